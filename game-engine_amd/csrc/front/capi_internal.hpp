@@ -1,0 +1,23 @@
+// Shared definitions behind the opaque C handles of include/game_hip.h.
+#pragma once
+#include "front.hpp"
+#include "../../../include/game_hip.h"
+#include <string>
+#include <vector>
+
+struct game_ir {
+    const game::Ir* ir = nullptr;
+    const std::vector<uint8_t>* blob = nullptr;
+    const std::string* json = nullptr;
+};
+
+struct game_program {
+    game::CompiledProgram prog;
+    std::vector<game_ir> irs;
+};
+
+namespace game {
+extern thread_local std::string g_last_error;
+int set_error(int code, const std::string& msg);
+int error_code_of(const CompileError& e);
+}  // namespace game

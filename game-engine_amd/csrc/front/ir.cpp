@@ -1,0 +1,358 @@
+// Lowering of a validated cinematic to the flat IR, its serialised forms, and the whole-source
+// entry point. The IR states, per stage, exactly what the reference's GLSL emitter would have
+// pasted for each argument (game-compiler/src/codegen/glsl.rs:261-531 reads its arguments through
+// stages.rs:25 `get_arg` with the parameter lists of builtins.rs:43-217).
+#include "front.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <set>
+
+namespace game {
+namespace {
+
+// palette names -> table index (glsl.rs:424-434); anything else is the default (rainbow, index 2)
+uint32_t palette_index(const std::string& name)
+{
+    static const char* names[] = {"fire", "ice", "rainbow", "ocean", "forest", "neon", "sunset", "plasma"};
+    for (uint32_t i = 0; i < 8; ++i) if (name == names[i]) return i;
+    return 2;
+}
+
+// Variables each stage declares at layer scope in the emitted GLSL (glsl.rs:261-531); stages that
+// wrap their text in `{ }` (star, polygon, rotate, ...) declare nothing visible afterwards.
+const char* const* declared_names(uint16_t id)
+{
+    static const char* const none[] = {nullptr};
+    static const char* const sdf[] = {"sdf_result", nullptr};
+    static const char* const box[] = {"box_d", "sdf_result", nullptr};
+    static const char* const cw[] = {"cw_dist", "sdf_result", nullptr};
+    static const char* const arc[] = {"arc_theta", nullptr};
+    static const char* const glow[] = {"glow_result", "color_result", nullptr};
+    static const char* const shade[] = {"aa", "color_result", nullptr};
+    static const char* const pal[] = {"pal_t", "color_result", nullptr};
+    static const char* const bloom[] = {"pp_lum", nullptr};
+    static const char* const grain[] = {"grain_noise", nullptr};
+    static const char* const vig[] = {"vig_dist", "vig_factor", nullptr};
+    static const char* const scan[] = {"scan_val", nullptr};
+    static const char* const grad[] = {"grad_t", "color_result", nullptr};
+    static const char* const spec[] = {"spec_x", "spec_r", "spec_g", "spec_b", "color_result", nullptr};
+    switch (id) {
+    case B_CIRCLE: case B_RING: case B_SIMPLEX: case B_VORONOI: case B_FBM: return sdf;
+    case B_BOX: return box;
+    case B_CONCENTRIC_WAVES: return cw;
+    case B_MASK_ARC: return arc;
+    case B_GLOW: case B_EMISSIVE: return glow;
+    case B_SHADE: return shade;
+    case B_PALETTE: return pal;
+    case B_BLOOM: return bloom;
+    case B_GRAIN: return grain;
+    case B_VIGNETTE: return vig;
+    case B_SCANLINES: return scan;
+    case B_GRADIENT: return grad;
+    case B_SPECTRUM: return spec;
+    default: return none;
+    }
+}
+
+float text_to_f32(const std::string& text) { return strtof(text.c_str(), nullptr); }
+
+LawFn law_fn(const std::string& n, size_t nargs, bool& ok)
+{
+    struct E { const char* n; LawFn f; size_t a; };
+    static const E tab[] = {
+        {"sin", LF_SIN, 1}, {"cos", LF_COS, 1}, {"tan", LF_TAN, 1}, {"abs", LF_ABS, 1}, {"sqrt", LF_SQRT, 1},
+        {"exp", LF_EXP, 1}, {"log", LF_LOG, 1}, {"floor", LF_FLOOR, 1}, {"ceil", LF_CEIL, 1}, {"fract", LF_FRACT, 1},
+        {"sign", LF_SIGN, 1}, {"exp2", LF_EXP2, 1}, {"log2", LF_LOG2, 1},
+        {"min", LF_MIN, 2}, {"max", LF_MAX, 2}, {"pow", LF_POW, 2}, {"step", LF_STEP, 2},
+        {"clamp", LF_CLAMP, 3}, {"mix", LF_MIX, 3}, {"smoothstep", LF_SMOOTHSTEP, 3},
+    };
+    for (const E& e : tab) if (n == e.n && nargs == e.a) { ok = true; return e.f; }
+    ok = false;
+    return LF_SIN;
+}
+
+void lower_law(const Expr& e, Ir& ir)
+{
+    auto push = [&](uint32_t op, float v = 0.0f, uint32_t fn = 0) {
+        IrLawOp o;
+        o.op = op; o.val = v; o.fn = fn;
+        ir.gravity.law.push_back(o);
+    };
+    switch (e.kind) {
+    case Expr::Number: push(LAW_NUM, text_to_f32(fmt_fixed6(e.num))); return;
+    case Expr::Ident:
+        if (e.s == "dist") push(LAW_DIST);
+        else if (e.s == "time") push(LAW_TIME);
+        else { ir.flags |= IRF_GRAVITY_IDENT; push(LAW_NUM, 0.0f); }
+        return;
+    case Expr::Bin: {
+        lower_law(e.kids[0], ir);
+        lower_law(e.kids[1], ir);
+        static const uint32_t ops[] = {LAW_ADD, LAW_SUB, LAW_MUL, LAW_DIV, LAW_POW, LAW_GT, LAW_LT};
+        push(ops[(int)e.op]);
+        return;
+    }
+    case Expr::Neg: lower_law(e.kids[0], ir); push(LAW_NEG); return;
+    case Expr::Paren: lower_law(e.kids[0], ir); return;
+    case Expr::Call: {
+        bool ok;
+        LawFn f = law_fn(e.s, e.args.size(), ok);
+        if (!ok) { ir.flags |= IRF_GRAVITY_IDENT; push(LAW_NUM, 0.0f); return; }
+        for (const Arg& a : e.args) lower_law(a.value, ir);
+        push(e.args.size() == 1 ? LAW_CALL1 : e.args.size() == 2 ? LAW_CALL2 : LAW_CALL3, 0.0f, f);
+        return;
+    }
+    default: push(LAW_NUM, 1.0f); return;   // gravity.rs:39 fallback
+    }
+}
+
+}  // namespace
+
+Ir lower_cinematic(const Cinematic& c)
+{
+    Ir ir;
+    ir.name = c.name;
+    ir.multi_layer = c.layers.size() > 1;
+    ir.uniforms = extract_uniforms(c);
+    std::map<std::string, uint32_t> uslot;
+    for (uint32_t i = 0; i < ir.uniforms.size(); ++i) uslot[ir.uniforms[i].name] = i;
+
+    bool any_pipeline = false;
+    for (const Layer& l : c.layers) {
+        IrLayer il;
+        il.name = l.name;
+        il.is_pipeline = l.is_pipeline;
+        il.has_memory = l.has_memory;
+        if (l.has_memory) {
+            ir.uses_memory = true;
+            il.decay_text = fmt_fixed6(l.memory);
+            il.decay = text_to_f32(il.decay_text);
+        }
+        il.stage_begin = (uint32_t)ir.stages.size();
+        if (l.is_pipeline) {
+            any_pipeline = true;
+            State st = State::Position;
+            std::set<std::string> declared;   // names visible at layer scope in the emitted GLSL
+            for (const Stage& s : l.stages) {
+                const Builtin* b = builtin_lookup(s.name);
+                if (!b) continue;   // unreachable after validation
+                IrStage is;
+                is.builtin = b->id;
+                is.name = b->name;
+                is.nargs = b->nparams;
+                for (uint32_t p = 0; p < b->nparams; ++p) {
+                    ArgText t = get_arg(s.args, b->params[p].name, p, b->name);
+                    IrArg& a = is.args[p];
+                    a.text = t.text;
+                    if (t.kind == ArgText::Literal) {
+                        a.kind = ARG_LIT;
+                        a.lit = text_to_f32(t.text);
+                    } else if (t.kind == ArgText::Ident) {
+                        if (b->id == B_PALETTE) {          // the name is matched as text, never evaluated
+                            a.kind = ARG_LIT; a.lit = 0.0f;
+                        } else if (t.text == "time") {
+                            a.kind = ARG_BUILTIN; a.slot = BU_TIME;
+                            ir.flags |= IRF_TIME_IDENT;
+                        } else if (uslot.count(t.text)) {
+                            a.kind = ARG_USER; a.slot = uslot[t.text];
+                        } else {
+                            a.kind = ARG_LIT; a.lit = 0.0f;
+                            ir.flags |= IRF_BUILTIN_IDENT;
+                        }
+                    } else {
+                        static const struct { const char* n; uint32_t slot; } dotted[] = {
+                            {"audio_bass", BU_AUDIO_BASS}, {"audio_mid", BU_AUDIO_MID}, {"audio_treble", BU_AUDIO_TREBLE},
+                            {"audio_energy", BU_AUDIO_ENERGY}, {"audio_beat", BU_AUDIO_BEAT},
+                            {"mouse_x", BU_MOUSE_X}, {"mouse_y", BU_MOUSE_Y},
+                        };
+                        bool found = false;
+                        for (auto& d : dotted) if (t.text == d.n) { a.kind = ARG_BUILTIN; a.slot = d.slot; found = true; }
+                        if (b->id == B_PALETTE) { a.kind = ARG_LIT; a.lit = 0.0f; found = true; }
+                        else ir.flags |= IRF_DOTTED_ARG;
+                        if (!found) { a.kind = ARG_LIT; a.lit = 0.0f; ir.flags |= IRF_UNKNOWN_DOTTED; }
+                    }
+                }
+                if (b->id == B_PALETTE) is.aux = palette_index(is.args[0].text);
+                // GLSL scoping facts of the emitted text (glsl.rs:261-531)
+                if (b->input == State::Sdf && !declared.count("sdf_result")) ir.flags |= IRF_COLOR_BEFORE_DECL;
+                if (b->input == State::Color && !declared.count("color_result")) ir.flags |= IRF_COLOR_BEFORE_DECL;
+                if (b->id == B_STAR || b->id == B_POLYGON) ir.flags |= IRF_BLOCK_SCOPED_SDF;
+                for (const char* const* d = declared_names(b->id); *d; ++d)
+                    if (!declared.insert(*d).second) ir.flags |= IRF_REDECLARED;
+                st = b->output;
+                ir.stages.push_back(std::move(is));
+            }
+            il.end_state = st;
+            if (st != State::Color) ir.flags |= IRF_NO_COLOR;
+        }
+        il.stage_count = (uint32_t)ir.stages.size() - il.stage_begin;
+        ir.layers.push_back(std::move(il));
+    }
+    if (!any_pipeline) ir.flags |= IRF_NO_OUTPUT;
+
+    if (c.has_gravity) {
+        ir.gravity.present = true;
+        ir.gravity.damping_text = fmt_f64_display(c.gravity.damping);   // `{damping}` (gravity.rs:92-95)
+        ir.gravity.damping = (float)c.gravity.damping;
+        ir.gravity.bounds = c.gravity.bounds;
+        ir.gravity.law_text = force_expr_text(c.gravity.force_law);
+        lower_law(c.gravity.force_law, ir);
+    }
+    return ir;
+}
+
+// ── serialisation ────────────────────────────────────────────────────────
+namespace {
+void put_u32(std::vector<uint8_t>& b, uint32_t v) { for (int i = 0; i < 4; ++i) b.push_back((uint8_t)(v >> (8 * i))); }
+void put_f32(std::vector<uint8_t>& b, float f) { uint32_t v; memcpy(&v, &f, 4); put_u32(b, v); }
+void put_str(std::vector<uint8_t>& b, const std::string& s, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) b.push_back(i + 1 < n && i < s.size() ? (uint8_t)s[i] : 0);
+}
+std::string json_escape(const std::string& s)
+{
+    std::string o;
+    for (unsigned char c : s) {
+        if (c == '"' || c == '\\') { o.push_back('\\'); o.push_back((char)c); }
+        else if (c == '\n') o += "\\n";
+        else if (c == '\t') o += "\\t";
+        else if (c == '\r') o += "\\r";
+        else if (c < 0x20) { char buf[8]; snprintf(buf, sizeof buf, "\\u%04x", c); o += buf; }
+        else o.push_back((char)c);
+    }
+    return o;
+}
+std::string f32_json(float f)
+{
+    if (f != f || f - f != 0.0f) return "null";
+    char buf[64];
+    snprintf(buf, sizeof buf, "%.9g", (double)f);
+    return buf;
+}
+}  // namespace
+
+std::vector<uint8_t> ir_serialize(const Ir& ir)
+{
+    std::vector<uint8_t> b;
+    put_u32(b, 0x31524947u);   // "GIR1"
+    put_u32(b, 0);             // total bytes, patched below
+    put_u32(b, (uint32_t)ir.layers.size());
+    put_u32(b, (uint32_t)ir.stages.size());
+    put_u32(b, (uint32_t)ir.uniforms.size());
+    put_u32(b, (uint32_t)ir.gravity.law.size());
+    put_u32(b, ir.flags);
+    put_u32(b, ir.multi_layer ? 1 : 0);
+    put_u32(b, ir.uses_memory ? 1 : 0);
+    put_u32(b, ir.gravity.present ? 1 : 0);
+    put_f32(b, ir.gravity.damping);
+    put_u32(b, (uint32_t)ir.gravity.bounds);
+    put_str(b, ir.name, 64);
+    for (const IrLayer& l : ir.layers) {
+        put_u32(b, l.is_pipeline ? 1 : 0);
+        put_u32(b, l.stage_begin);
+        put_u32(b, l.stage_count);
+        put_u32(b, l.has_memory ? 1 : 0);
+        put_f32(b, l.decay);
+        put_u32(b, (uint32_t)l.end_state);
+        put_u32(b, 0);
+        put_u32(b, 0);
+    }
+    for (const IrStage& s : ir.stages) {
+        put_u32(b, s.builtin);
+        put_u32(b, s.nargs);
+        put_u32(b, s.aux);
+        put_u32(b, 0);
+        for (int i = 0; i < 4; ++i) {
+            put_u32(b, s.args[i].kind);
+            put_u32(b, s.args[i].slot);
+            put_f32(b, s.args[i].lit);
+            put_u32(b, 0);
+        }
+    }
+    for (const UniformInfo& u : ir.uniforms) {
+        put_f32(b, (float)u.def);
+        put_str(b, u.name, 60);
+    }
+    for (const IrLawOp& o : ir.gravity.law) {
+        put_u32(b, o.op);
+        put_f32(b, o.val);
+        put_u32(b, o.fn);
+        put_u32(b, 0);
+    }
+    uint32_t total = (uint32_t)b.size();
+    for (int i = 0; i < 4; ++i) b[4 + i] = (uint8_t)(total >> (8 * i));
+    return b;
+}
+
+std::string ir_to_json(const Ir& ir)
+{
+    std::string j = "{";
+    j += "\"name\":\"" + json_escape(ir.name) + "\"";
+    j += ",\"multi_layer\":" + std::string(ir.multi_layer ? "true" : "false");
+    j += ",\"uses_memory\":" + std::string(ir.uses_memory ? "true" : "false");
+    j += ",\"flags\":" + std::to_string(ir.flags);
+    j += ",\"uniforms\":[";
+    for (size_t i = 0; i < ir.uniforms.size(); ++i) {
+        if (i) j += ",";
+        char buf[64];
+        snprintf(buf, sizeof buf, "%.17g", ir.uniforms[i].def);
+        j += "{\"name\":\"" + json_escape(ir.uniforms[i].name) + "\",\"default\":" + buf + "}";
+    }
+    j += "],\"layers\":[";
+    for (size_t li = 0; li < ir.layers.size(); ++li) {
+        const IrLayer& l = ir.layers[li];
+        if (li) j += ",";
+        j += "{\"name\":\"" + json_escape(l.name) + "\",\"pipeline\":" + (l.is_pipeline ? "true" : "false");
+        j += ",\"memory\":" + (l.has_memory ? "\"" + l.decay_text + "\"" : std::string("null"));
+        j += ",\"end_state\":\"" + std::string(state_name(l.end_state)) + "\",\"stages\":[";
+        for (uint32_t si = 0; si < l.stage_count; ++si) {
+            const IrStage& s = ir.stages[l.stage_begin + si];
+            if (si) j += ",";
+            j += "{\"name\":\"" + s.name + "\",\"id\":" + std::to_string(s.builtin) + ",\"aux\":" + std::to_string(s.aux) + ",\"args\":[";
+            for (uint32_t a = 0; a < s.nargs; ++a) {
+                if (a) j += ",";
+                const IrArg& ia = s.args[a];
+                const char* kind = ia.kind == ARG_LIT ? "lit" : ia.kind == ARG_USER ? "user" : "builtin";
+                j += "{\"kind\":\"" + std::string(kind) + "\",\"slot\":" + std::to_string(ia.slot) + ",\"lit\":" + f32_json(ia.lit) +
+                     ",\"text\":\"" + json_escape(ia.text) + "\"}";
+            }
+            j += "]}";
+        }
+        j += "]}";
+    }
+    j += "],\"gravity\":";
+    if (ir.gravity.present) {
+        j += "{\"damping\":\"" + ir.gravity.damping_text + "\",\"bounds\":" + std::to_string((int)ir.gravity.bounds);
+        j += ",\"law\":\"" + json_escape(ir.gravity.law_text) + "\",\"ops\":" + std::to_string(ir.gravity.law.size()) + "}";
+    } else {
+        j += "null";
+    }
+    j += "}";
+    return j;
+}
+
+// ── whole-source entry point (lib.rs:117-155) ────────────────────────────
+CompileError compile_source(const std::string& src, CompiledProgram& out)
+{
+    out = CompiledProgram{};
+    std::vector<Token> toks;
+    CompileError e = lex(src, toks);
+    if (!e.ok()) return e;
+    e = parse(std::move(toks), out.ast);
+    if (!e.ok()) return e;
+    out.warnings = check_program(out.ast);
+    for (Cinematic& c : out.ast.cinematics) (void)expand_defines(c);   // result ignored, like `let _ =` (lib.rs:122)
+    for (Cinematic& c : out.ast.cinematics) optimize_cinematic(c);
+    for (const Cinematic& c : out.ast.cinematics) {
+        e = validate_cinematic(c);
+        if (!e.ok()) return e;
+        out.irs.push_back(lower_cinematic(c));
+        out.blobs.push_back(ir_serialize(out.irs.back()));
+        out.jsons.push_back(ir_to_json(out.irs.back()));
+    }
+    return CompileError{};
+}
+
+}  // namespace game

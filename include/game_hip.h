@@ -1,0 +1,164 @@
+/* game_hip.h — C ABI of libgame_hip.so, the MI355X (gfx950) render path for GAME cinematics.
+ *
+ * The reference compiler (runyourempire/game-engine, Rust) has no FFI of its own: its seam is the
+ * Rust function boundary `game_compiler::compile` -> `codegen::generate` -> `ShaderOutput`, whose
+ * GLSL text a browser GPU then executes once per pixel. This library replaces everything below
+ * that seam: it takes .game source (or the resolved IR), and renders RGBA8 frames, memory-feedback
+ * frames and gravity particle steps on the GPU. Each entry point names the reference interface it
+ * stands in for. All functions return 0 on success; see GAME_E_* for failures. After a non-zero
+ * return `game_last_error()` holds the message (thread-local, valid until the next call on the
+ * same thread).
+ *
+ * Threading: a game_program / game_ir is immutable after creation and may be shared. A
+ * game_hip_ctx belongs to one GPU and must be driven by one host thread at a time; distinct
+ * contexts may be driven concurrently (one per GPU), which mirrors the reference's single-threaded
+ * render() per renderer instance (game-compiler/src/runtime/helpers.rs:214).
+ */
+#ifndef GAME_HIP_H
+#define GAME_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct game_program game_program; /* parsed + optimised + validated source: N cinematics */
+typedef struct game_ir game_ir;           /* one cinematic's resolved IR (owned by its program)  */
+typedef struct game_hip_ctx game_hip_ctx; /* device state for one cinematic at one resolution    */
+
+/* Return codes. 1..10 are the reference's ErrorCode E001..E010 (game-compiler/src/error.rs:90-111). */
+enum {
+    GAME_OK = 0,
+    GAME_E001_UNKNOWN_STAGE = 1,
+    GAME_E002_TYPE_MISMATCH = 2,
+    GAME_E003_PARSE = 3,
+    GAME_E_LEX = 64,        /* CompileError::LexError (carries no code in the reference)          */
+    GAME_E_VALIDATION = 65, /* CompileError::ValidationError without a code (cast errors)          */
+    GAME_E_CODEGEN = 66,    /* CompileError::CodegenError                                          */
+    GAME_E_ARGUMENT = 80,   /* bad argument to this library                                        */
+    GAME_E_HIP = 81,        /* HIP runtime or hiprtc failure                                       */
+    GAME_E_NO_DEVICE = 82,  /* no usable GPU / HIP runtime not initialisable                       */
+    GAME_E_UNSUPPORTED = 83 /* cinematic has no such part (e.g. particles without a gravity block) */
+};
+
+const char* game_last_error(void);
+
+/* ── front end ─────────────────────────────────────────────────────────────────────────────
+ * game_front_compile replaces game_compiler::compile (game-compiler/src/lib.rs:117) up to and
+ * including codegen::generate's validation (game-compiler/src/codegen/mod.rs:138-141): lex, parse,
+ * expand_defines, optimize_cinematic, validate, extract_uniforms. The error text in
+ * game_last_error() is the reference's Display text for the same failure. */
+int game_front_compile(const char* src, size_t len, game_program** out);
+void game_program_free(game_program* p);
+size_t game_program_cinematic_count(const game_program* p);
+const game_ir* game_program_ir(const game_program* p, size_t index);
+/* game_compiler::check (lib.rs:83): semantic warnings, run on the parsed (unexpanded) program. */
+size_t game_program_warning_count(const game_program* p);
+const char* game_program_warning(const game_program* p, size_t index);
+/* error.rs:296 render_with_source for the last front-end error of this thread ("" if none). */
+const char* game_last_error_rendered(void);
+
+/* game_compiler::lex (lib.rs:76): number of tokens, and per token its byte span and display text. */
+int game_front_lex(const char* src, size_t len, size_t* ntokens, size_t* spans /* 2*cap */, size_t cap);
+/* game_compiler::list_builtins (lib.rs:102): "name|Input|Output|param,param,..." per builtin. */
+size_t game_builtin_count(void);
+const char* game_builtin_describe(size_t index);
+
+/* ── IR accessors ──────────────────────────────────────────────────────────────────────────
+ * The IR is what codegen::generate would have frozen into shader text: ShaderOutput.name,
+ * .uniforms (codegen/mod.rs:29-48), the per-stage argument text of stages.rs:25 get_arg, the
+ * memory decay literal (memory.rs:38-45) and the gravity force law (gravity.rs:10-41). */
+const char* game_ir_name(const game_ir* ir);
+const char* game_ir_json(const game_ir* ir);                /* full dump, UTF-8 JSON */
+size_t game_ir_blob(const game_ir* ir, const void** data);  /* flat blob, layout below */
+uint32_t game_ir_uniform_count(const game_ir* ir);
+const char* game_ir_uniform_name(const game_ir* ir, uint32_t i);
+double game_ir_uniform_default(const game_ir* ir, uint32_t i);
+uint32_t game_ir_flags(const game_ir* ir);                  /* GAME_IRF_* */
+int game_ir_uses_memory(const game_ir* ir);
+int game_ir_has_gravity(const game_ir* ir);
+/* Floats per frame in the uniform table: 10 built-ins + user uniforms
+ * [time, audio_bass, audio_mid, audio_treble, audio_energy, audio_beat, res.x, res.y, mouse.x,
+ *  mouse.y, user...] — the order GameRendererGL.render() uploads them (runtime/helpers.rs:222-232). */
+uint32_t game_ir_frame_floats(const game_ir* ir);
+/* Fills one frame's uniform row with the reference's defaults: time = t, audio = 0, resolution =
+ * (w, h), mouse = 0, user uniforms = their declared defaults. */
+void game_ir_default_uniforms(const game_ir* ir, float time_s, uint32_t w, uint32_t h, float* row);
+
+/* Places where the reference's emitted GLSL does not compile or leaves a value undefined; the IR
+ * then carries the evident intent (see front.hpp IrFlag for the per-bit meaning). */
+enum {
+    GAME_IRF_DOTTED_ARG = 1u << 0, GAME_IRF_TIME_IDENT = 1u << 1, GAME_IRF_BUILTIN_IDENT = 1u << 2,
+    GAME_IRF_BLOCK_SCOPED_SDF = 1u << 3, GAME_IRF_REDECLARED = 1u << 4, GAME_IRF_NO_COLOR = 1u << 5,
+    GAME_IRF_UNKNOWN_DOTTED = 1u << 6, GAME_IRF_NO_OUTPUT = 1u << 7, GAME_IRF_GRAVITY_IDENT = 1u << 8,
+    GAME_IRF_USE_BEFORE_DECL = 1u << 9
+};
+
+/* Blob layout (little-endian, every field 4 bytes unless noted):
+ *   header : magic 'GIR1', total_bytes, n_layers, n_stages, n_uniforms, n_law_ops, flags,
+ *            multi_layer, uses_memory, gravity_present, gravity_damping(f32), gravity_bounds
+ *            (0 reflect, 1 wrap, 2 none), name[64]
+ *   layer  : is_pipeline, stage_begin, stage_count, has_memory, decay(f32), end_state
+ *            (0 Position, 1 Sdf, 2 Color), 0, 0                                   (32 bytes)
+ *   stage  : builtin_id, nargs, aux(palette index), 0, then 4 x {kind, slot, lit(f32), 0}
+ *            kind 0 = literal, 1 = user uniform slot, 2 = built-in uniform slot   (80 bytes)
+ *   uniform: default(f32), name[60]                                               (64 bytes)
+ *   law op : op, value(f32), fn, 0                                                (16 bytes)
+ * Built-in uniform slot 0 used as a stage argument means the shader's wrapped time
+ * `fract(u_time / 120) * 120` (glsl.rs:56), not the raw u_time. */
+
+/* ── GPU render path ───────────────────────────────────────────────────────────────────────
+ * game_hip_create replaces GameRendererGL.init (runtime/helpers.rs:148-183): where the browser
+ * compiles the emitted GLSL, this assembles one fused per-pixel kernel for the cinematic from
+ * hand-written gfx950 device functions and compiles it with hiprtc. `device` is a HIP ordinal. */
+int game_hip_device_count(int* count);
+int game_hip_create(const game_ir* ir, uint32_t width, uint32_t height, int device, game_hip_ctx** out);
+void game_hip_destroy(game_hip_ctx* ctx);
+
+/* game_hip_render replaces GameRendererGL.render (runtime/helpers.rs:214-235) for `nframes`
+ * consecutive frames. `uniforms` holds nframes rows of game_ir_frame_floats() floats (host memory).
+ * Frames are RGBA8, row 0 = TOP row of the image (the GL framebuffer's row 0 is the bottom row;
+ * the flip happens when the kernel stores a pixel). Frames land in a device ring of `ring_frames`
+ * slots (frame k of this call -> slot (first_slot + k) % ring_frames); when rgba8_host is non-NULL
+ * every frame is also copied to host memory (nframes * w * h * 4 bytes; needs nframes <=
+ * ring_frames). Cinematics with `memory:` layers are frame-serial: each frame reads the previous
+ * frame's RGBA8 output (zero before the first frame; see game_hip_reset_memory). */
+int game_hip_set_ring(game_hip_ctx* ctx, uint32_t ring_frames);
+int game_hip_render(game_hip_ctx* ctx, const float* uniforms, uint32_t nframes, uint8_t* rgba8_host);
+/* Same, restricted to image rows [row0, row0 + rows) (top-first): the unit of work of one rank
+ * when a memory/feedback cinematic is sharded into horizontal bands. Rows outside the band are
+ * not touched. rgba8_host, when non-NULL, receives only the band (nframes * rows * w * 4). */
+int game_hip_render_band(game_hip_ctx* ctx, const float* uniforms, uint32_t nframes, uint32_t row0,
+                         uint32_t rows, uint8_t* rgba8_host);
+int game_hip_reset_memory(game_hip_ctx* ctx);          /* previous-frame store := 0 */
+int game_hip_sync(game_hip_ctx* ctx);                  /* wait for the context's stream */
+void* game_hip_frame_ptr(game_hip_ctx* ctx, uint32_t slot);   /* device pointer of a ring slot */
+uint32_t game_hip_ring_frames(const game_hip_ctx* ctx);
+/* Device time of the kernels of the last render call, from HIP events recorded on the context's
+ * stream around the launches (milliseconds), and the number of launches it covers. */
+int game_hip_last_kernel_ms(game_hip_ctx* ctx, float* ms, uint32_t* launches);
+/* Source text of the generated kernel (for inspection and tests). */
+const char* game_hip_kernel_source(const game_hip_ctx* ctx);
+/* Compile the generated kernel for gfx950 without touching a device (build-time check). */
+int game_hip_compile_only(const game_ir* ir, size_t* code_bytes);
+
+/* ── gravity particles ─────────────────────────────────────────────────────────────────────
+ * Replaces GameGravitySim.init/dispatch (game-compiler/src/codegen/gravity.rs:123-191) and the
+ * compute shader of gravity.rs:43-120. Particles are stored SoA on the device (x, y, vx, vy).
+ * `first`/`count` select the index range this context integrates (all-pairs against all n
+ * positions); with count < n the caller exchanges positions between ranks after each step
+ * (game_hip_particles_positions gives the device arrays to all-gather). */
+int game_hip_particles_init(game_hip_ctx* ctx, uint32_t n, const float* pos_xy_host /* 2n */,
+                            const float* vel_xy_host /* 2n or NULL = 0 */);
+int game_hip_particles_seed(game_hip_ctx* ctx, uint32_t n, uint64_t seed); /* SplitMix64 init */
+int game_hip_particles_step(game_hip_ctx* ctx, float dt, uint32_t steps, uint32_t first, uint32_t count);
+int game_hip_particles_read(game_hip_ctx* ctx, float* pos_xy_host, float* vel_xy_host);
+int game_hip_particles_positions(game_hip_ctx* ctx, float** x_dev, float** y_dev);
+int game_hip_particles_time(game_hip_ctx* ctx, float* sim_time);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAME_HIP_H */

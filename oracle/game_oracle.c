@@ -1,0 +1,659 @@
+/* game_oracle.c — TEST INFRASTRUCTURE. CPU restatement of the per-pixel fragment pipeline,
+ * memory feedback and gravity step that the reference compiler emits as shader text and a browser
+ * GPU executes. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this;
+ * the shipped render path never does.
+ *
+ * PARITY UNPINNED: the reference holds no pixel or particle golden vectors (its tests assert on
+ * emitted text only) and its executor (a browser GLSL/WGSL implementation) cannot run here. This
+ * file follows the emitted GLSL ES 3.00 text operation by operation, in scalar FP32, one rounding
+ * per GLSL operator (compile with -ffp-contract=off), with the function definitions of gm_math.h.
+ *
+ *   fragment prologue ............ game-compiler/src/codegen/glsl.rs:53-61, vertex :541-555
+ *   hash2 / noise2 / fbm2 ........ glsl.rs:134-150, :155-169
+ *   simplex2d / voronoi2d ........ glsl.rs:172-199, :201-220
+ *   stages ....................... glsl.rs:261-531 (cited per case below)
+ *   layer compositing ............ glsl.rs:66-77, :228-259
+ *   memory mix ................... game-compiler/src/codegen/memory.rs:38-45, runtime :102-147
+ *   gravity step ................. game-compiler/src/codegen/gravity.rs:43-120
+ *
+ * Input is the flat IR blob produced by the front end (layout in include/game_hip.h).
+ */
+#include "gm_math.h"
+#include <pthread.h>
+#include <stdlib.h>
+#include <stdio.h>
+
+/* builtin ids: order of the reference's BUILTINS registry (builtins.rs:221-293) */
+enum {
+    B_CIRCLE, B_RING, B_STAR, B_FBM, B_SIMPLEX, B_GLOW, B_SHADE, B_EMISSIVE, B_TINT, B_BLOOM, B_GRAIN,
+    B_TRANSLATE, B_ROTATE, B_SCALE, B_MASK_ARC, B_THRESHOLD, B_TWIST, B_MIRROR, B_REPEAT, B_GRADIENT,
+    B_BLEND, B_VIGNETTE, B_VORONOI, B_ONION, B_DOMAIN_WARP, B_CURL_NOISE, B_BOX, B_POLYGON,
+    B_CONCENTRIC_WAVES, B_ROUND, B_TONEMAP, B_SCANLINES, B_CHROMATIC, B_SATURATE_COLOR, B_GLITCH,
+    B_DISPLACE, B_SPECTRUM, B_PALETTE
+};
+enum { BU_TIME = 0, BU_BASS, BU_MID, BU_TREBLE, BU_ENERGY, BU_BEAT, BU_RES_X, BU_RES_Y, BU_MOUSE_X, BU_MOUSE_Y, BU_COUNT };
+
+typedef struct { uint32_t kind, slot; float lit; uint32_t pad; } ir_arg;
+typedef struct { uint32_t builtin, nargs, aux, pad; ir_arg args[4]; } ir_stage;
+typedef struct { uint32_t is_pipeline, stage_begin, stage_count, has_memory; float decay; uint32_t end_state, pad0, pad1; } ir_layer;
+typedef struct { uint32_t op; float val; uint32_t fn, pad; } ir_law;
+typedef struct {
+    uint32_t magic, total, n_layers, n_stages, n_uniforms, n_law, flags, multi_layer, uses_memory, gravity_present;
+    float damping; uint32_t bounds; char name[64];
+} ir_header;
+
+typedef struct {
+    const ir_header* h;
+    const ir_layer* layers;
+    const ir_stage* stages;
+    const ir_law* law;
+} ir_view;
+
+static int ir_open(const void* blob, size_t len, ir_view* v)
+{
+    if (len < sizeof(ir_header)) return -1;
+    const ir_header* h = (const ir_header*)blob;
+    if (h->magic != 0x31524947u || h->total != len) return -1;
+    size_t need = sizeof(ir_header) + (size_t)h->n_layers * sizeof(ir_layer) + (size_t)h->n_stages * sizeof(ir_stage) +
+                  (size_t)h->n_uniforms * 64 + (size_t)h->n_law * sizeof(ir_law);
+    if (need != len) return -1;
+    const char* p = (const char*)blob + sizeof(ir_header);
+    v->h = h;
+    v->layers = (const ir_layer*)p; p += (size_t)h->n_layers * sizeof(ir_layer);
+    v->stages = (const ir_stage*)p; p += (size_t)h->n_stages * sizeof(ir_stage);
+    p += (size_t)h->n_uniforms * 64;
+    v->law = (const ir_law*)p;
+    return 0;
+}
+
+/* ── noise helpers ─────────────────────────────────────────────────────────────────────── */
+static float hash2(float px, float py)   /* glsl.rs:134-138 */
+{
+    float x = gm_fract(px * 0.1031f);
+    float y = gm_fract(py * 0.1031f);
+    float z = gm_fract(px * 0.1031f);
+    float d = x * (y + 33.33f) + y * (z + 33.33f) + z * (x + 33.33f);   /* dot(p3, p3.yzx + 33.33) */
+    x = x + d; y = y + d; z = z + d;
+    return gm_fract((x + y) * z);
+}
+
+static float noise2(float px, float py)   /* glsl.rs:141-150 */
+{
+    float ix = gm_floor(px), iy = gm_floor(py);
+    float fx = gm_fract(px), fy = gm_fract(py);
+    float ux = fx * fx * (3.0f - 2.0f * fx);
+    float uy = fy * fy * (3.0f - 2.0f * fy);
+    float a = hash2(ix, iy);
+    float b = hash2(ix + 1.0f, iy + 0.0f);
+    float c = hash2(ix + 0.0f, iy + 1.0f);
+    float d = hash2(ix + 1.0f, iy + 1.0f);
+    return gm_mix(gm_mix(a, b, ux), gm_mix(c, d, ux), uy) * 2.0f - 1.0f;
+}
+
+static int to_int_octaves(float o)   /* int(x): truncation; out-of-range values are clamped to [0, 32] */
+{
+    if (!(o >= 1.0f)) return 0;
+    if (o >= 32.0f) return 32;
+    return (int)o;
+}
+
+static float fbm2(float px, float py, int octaves, float persistence, float lacunarity)   /* glsl.rs:155-169 */
+{
+    float value = 0.0f, amplitude = 1.0f, frequency = 1.0f, max_val = 0.0f;
+    float qx = px, qy = py;
+    for (int i = 0; i < octaves; i++) {
+        value = value + noise2(qx * frequency, qy * frequency) * amplitude;
+        max_val = max_val + amplitude;
+        amplitude = amplitude * persistence;
+        frequency = frequency * lacunarity;
+        float nx = qx * 0.8f - qy * 0.6f;
+        float ny = qx * 0.6f + qy * 0.8f;
+        qx = nx; qy = ny;
+    }
+    return value / max_val;
+}
+
+static float permute1(float x) { return gm_mod((x * 34.0f + 1.0f) * x, 289.0f); }   /* glsl.rs:173-175 */
+
+static float simplex2d(float vx, float vy)   /* glsl.rs:176-198 */
+{
+    const float Cx = 0.211324865405187f, Cy = 0.366025403784439f, Cz = -0.577350269189626f, Cw = 0.024390243902439f;
+    float dv = vx * Cy + vy * Cy;
+    float ix = gm_floor(vx + dv), iy = gm_floor(vy + dv);
+    float di = ix * Cx + iy * Cx;
+    float x0x = vx - ix + di, x0y = vy - iy + di;
+    float i1x = (x0x > x0y) ? 1.0f : 0.0f;
+    float i1y = (x0x > x0y) ? 0.0f : 1.0f;
+    float x12x = x0x + Cx, x12y = x0y + Cx, x12z = x0x + Cz, x12w = x0y + Cz;
+    x12x = x12x - i1x; x12y = x12y - i1y;
+    ix = gm_mod(ix, 289.0f); iy = gm_mod(iy, 289.0f);
+    float p0 = permute1(permute1(iy + 0.0f) + ix + 0.0f);
+    float p1 = permute1(permute1(iy + i1y) + ix + i1x);
+    float p2 = permute1(permute1(iy + 1.0f) + ix + 1.0f);
+    float m0 = gm_max(0.5f - (x0x * x0x + x0y * x0y), 0.0f);
+    float m1 = gm_max(0.5f - (x12x * x12x + x12y * x12y), 0.0f);
+    float m2 = gm_max(0.5f - (x12z * x12z + x12w * x12w), 0.0f);
+    m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
+    m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
+    float xv0 = 2.0f * gm_fract(p0 * Cw) - 1.0f;
+    float xv1 = 2.0f * gm_fract(p1 * Cw) - 1.0f;
+    float xv2 = 2.0f * gm_fract(p2 * Cw) - 1.0f;
+    float h0 = gm_abs(xv0) - 0.5f, h1 = gm_abs(xv1) - 0.5f, h2 = gm_abs(xv2) - 0.5f;
+    float ox0 = gm_floor(xv0 + 0.5f), ox1 = gm_floor(xv1 + 0.5f), ox2 = gm_floor(xv2 + 0.5f);
+    float a00 = xv0 - ox0, a01 = xv1 - ox1, a02 = xv2 - ox2;
+    m0 = m0 * (1.79284291400159f - 0.85373472095314f * (a00 * a00 + h0 * h0));
+    m1 = m1 * (1.79284291400159f - 0.85373472095314f * (a01 * a01 + h1 * h1));
+    m2 = m2 * (1.79284291400159f - 0.85373472095314f * (a02 * a02 + h2 * h2));
+    float g0 = a00 * x0x + h0 * x0y;
+    float g1 = a01 * x12x + h1 * x12y;
+    float g2 = a02 * x12z + h2 * x12w;
+    return 130.0f * (m0 * g0 + m1 * g1 + m2 * g2);
+}
+
+static float voronoi2d(float px, float py, float scale)   /* glsl.rs:202-219 */
+{
+    float psx = px * scale, psy = py * scale;
+    float ipx = gm_floor(psx), ipy = gm_floor(psy);
+    float fpx = gm_fract(psx), fpy = gm_fract(psy);
+    float d = 1.0f;
+    for (int y = -1; y <= 1; y++) {
+        for (int x = -1; x <= 1; x++) {
+            float nx = (float)x, ny = (float)y;
+            float cx = ipx + nx, cy = ipy + ny;
+            float hx = gm_fract(gm_sin(cx * 127.1f + cy * 311.7f) * 43758.5453f);
+            float hy = gm_fract(gm_sin(cx * 269.5f + cy * 183.3f) * 43758.5453f);
+            float ptx = nx + hx - fpx, pty = ny + hy - fpy;
+            d = gm_min(d, ptx * ptx + pty * pty);
+        }
+    }
+    return sqrtf(d);
+}
+
+static float apply_glow(float d, float intensity)   /* glsl.rs:102-107 */
+{
+    float core = gm_smoothstep(0.005f, -0.005f, d);
+    float halo = intensity / (1.0f + gm_max(d, 0.0f) * gm_max(d, 0.0f) * intensity * intensity * 16.0f);
+    return core + halo;
+}
+
+/* palette table (glsl.rs:424-434): a, b, c, d per named set */
+static const float PALETTES[8][12] = {
+    /* fire    */ {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 1.0f, 1.0f, 1.0f, 0.00f, 0.10f, 0.20f},
+    /* ice     */ {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 1.0f, 1.0f, 1.0f, 0.30f, 0.20f, 0.20f},
+    /* rainbow */ {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 1.0f, 1.0f, 1.0f, 0.00f, 0.33f, 0.67f},
+    /* ocean   */ {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 1.0f, 0.7f, 0.4f, 0.00f, 0.15f, 0.20f},
+    /* forest  */ {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 1.0f, 1.0f, 0.5f, 0.80f, 0.90f, 0.30f},
+    /* neon    */ {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 2.0f, 1.0f, 0.0f, 0.50f, 0.20f, 0.25f},
+    /* sunset  */ {0.8f, 0.5f, 0.4f, 0.2f, 0.4f, 0.2f, 2.0f, 1.0f, 1.0f, 0.00f, 0.25f, 0.25f},
+    /* plasma  */ {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 1.0f, 1.0f, 1.0f, 0.00f, 0.10f, 0.20f},
+};
+
+/* ── one pixel ─────────────────────────────────────────────────────────────────────────── */
+typedef struct {
+    float time;      /* fract(u_time / 120) * 120 */
+    float aspect;    /* u_resolution.x / u_resolution.y */
+    const float* row;/* this frame's uniform row: 10 built-ins then user uniforms */
+} frame_consts;
+
+static inline float arg_value(const ir_arg* a, const frame_consts* fc)
+{
+    if (a->kind == 0) return a->lit;
+    if (a->kind == 1) return fc->row[BU_COUNT + a->slot];
+    return a->slot == BU_TIME ? fc->time : fc->row[a->slot];
+}
+
+static inline uint32_t pack_unorm8(float c)   /* framebuffer write: round(clamp(c, 0, 1) * 255) */
+{
+    float t = gm_min(gm_max(c, 0.0f), 1.0f);
+    return (uint32_t)(t * 255.0f + 0.5f);
+}
+
+/* uvx, uvy: `uv` of glsl.rs:54. prev: previous frame's RGBA8 texel at this pixel. out: RGBA floats. */
+static void shade_pixel(const ir_view* ir, const frame_consts* fc, float uvx, float uvy, uint32_t prev, float out[4])
+{
+    const float time = fc->time;
+    float fin_r = 0.0f, fin_g = 0.0f, fin_b = 0.0f, fin_a = 1.0f;   /* final_color (glsl.rs:68) */
+    float frag[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+    const int multi = (int)ir->h->multi_layer;
+
+    for (uint32_t li = 0; li < ir->h->n_layers; li++) {
+        const ir_layer* L = &ir->layers[li];
+        if (!L->is_pipeline) continue;                         /* glsl.rs:229-232 */
+        float px = uvx * fc->aspect, py = uvy;                 /* glsl.rs:240 */
+        float sdf = 0.0f;
+        float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;
+        for (uint32_t si = 0; si < L->stage_count; si++) {
+            const ir_stage* S = &ir->stages[L->stage_begin + si];
+            const float a0 = arg_value(&S->args[0], fc), a1 = arg_value(&S->args[1], fc);
+            const float a2 = arg_value(&S->args[2], fc), a3 = arg_value(&S->args[3], fc);
+            switch (S->builtin) {
+            /* SDF generators */
+            case B_CIRCLE: sdf = gm_length2(px, py) - a0; break;                                   /* :265-268, :96-100 */
+            case B_RING: sdf = gm_abs(gm_length2(px, py) - a0) - a1; break;                        /* :269-273 */
+            case B_STAR: {                                                                         /* :274-288 */
+                float an = 3.14159265359f / a0;
+                float a = gm_atan2(py, px);
+                float sector = gm_mod(a + an, 2.0f * an) - an;
+                float len = gm_length2(px, py);
+                float spx = gm_cos(sector) * len, spy = gm_abs(gm_sin(sector)) * len;
+                float apx = a1, apy = 0.0f;
+                float bpx = a2 * gm_cos(an), bpy = a2 * gm_sin(an);
+                float bax = bpx - apx, bay = bpy - apy;
+                float t = gm_clamp(((spx - apx) * bax + (spy - apy) * bay) / (bax * bax + bay * bay), 0.0f, 1.0f);
+                sdf = gm_length2(spx - apx - bax * t, spy - apy - bay * t);
+                break;
+            }
+            case B_BOX: {                                                                          /* :289-294 */
+                float dx = gm_abs(px) - a0, dy = gm_abs(py) - a1;
+                sdf = gm_length2(gm_max(dx, 0.0f), gm_max(dy, 0.0f)) + gm_min(gm_max(dx, dy), 0.0f);
+                break;
+            }
+            case B_POLYGON: {                                                                      /* :295-304 */
+                float n = a0;
+                float a = gm_atan2(py, px);
+                float r = gm_length2(px, py);
+                float an = 6.28318530718f / n;
+                float sector = gm_cos(gm_floor(0.5f + a / an) * an - a) * r;
+                sdf = sector - a1;
+                break;
+            }
+            case B_SIMPLEX: sdf = simplex2d(px * a0, py * a0); break;                              /* :305-308 */
+            case B_VORONOI: sdf = voronoi2d(px, py, a0); break;                                    /* :309-312 */
+            case B_CONCENTRIC_WAVES: {                                                             /* :313-319 */
+                float dist = gm_length2(px, py);
+                sdf = a0 * gm_sin(dist * a2 * 6.28318530718f - time * a1);
+                break;
+            }
+            case B_FBM: sdf = fbm2(px * a0, py * a0, to_int_octaves(a1), a2, a3); break;            /* :320-326 */
+
+            /* transforms */
+            case B_ROTATE: {                                                                       /* :329-334 */
+                float rc = gm_cos(a0), rs = gm_sin(a0);
+                float nx = px * rc - py * rs, ny = px * rs + py * rc;
+                px = nx; py = ny;
+                break;
+            }
+            case B_TRANSLATE: px = px - a0; py = py - a1; break;                                   /* :335-339 */
+            case B_SCALE: px = px / a0; py = py / a0; break;                                       /* :340-343 */
+            case B_TWIST: {                                                                        /* :344-349 */
+                float tw = py * a0;
+                float c = gm_cos(tw), s = gm_sin(tw);
+                float nx = px * c - py * s, ny = px * s + py * c;
+                px = nx; py = ny;
+                break;
+            }
+            case B_MIRROR:                                                                         /* :350-354 */
+                if (a0 < 0.5f) px = gm_abs(px); else py = gm_abs(py);
+                break;
+            case B_REPEAT: {                                                                       /* :355-361 */
+                float ra = 6.28318530718f / a0;
+                float a = gm_atan2(py, px);
+                a = gm_mod(a + ra * 0.5f, ra) - ra * 0.5f;
+                float len = gm_length2(px, py);
+                px = gm_cos(a) * len; py = gm_sin(a) * len;
+                break;
+            }
+            case B_DOMAIN_WARP: {                                                                  /* :362-366 */
+                float n0 = noise2(px * a1, py * a1);
+                float n1 = noise2(px * a1 + 5.2f, py * a1 + 1.3f);
+                px = px + n0 * a0; py = py + n1 * a0;
+                break;
+            }
+            case B_CURL_NOISE: {                                                                   /* :367-377 */
+                const float eps = 0.001f;
+                float n0 = noise2(px * a0 + 0.0f, py * a0 + eps);
+                float n1 = noise2(px * a0 - 0.0f, py * a0 - eps);
+                float n2 = noise2(px * a0 + eps, py * a0 + 0.0f);
+                float n3 = noise2(px * a0 - eps, py * a0 - 0.0f);
+                float cx = (n0 - n1) / (2.0f * eps);
+                float cy = -(n2 - n3) / (2.0f * eps);
+                float len = gm_length2(cx, cy);
+                px = px + cx / len * a1; py = py + cy / len * a1;                                  /* normalize = v / length(v) */
+                break;
+            }
+            case B_DISPLACE: {                                                                     /* :378-381 */
+                float t5 = time * 0.5f;
+                float n0 = noise2(px * 3.0f + t5, py * 3.0f + t5);
+                float n1 = noise2(px * 3.0f + 5.2f + t5, py * 3.0f + 1.3f + t5);
+                px = px + n0 * a0; py = py + n1 * a0;
+                break;
+            }
+
+            /* SDF modifiers */
+            case B_MASK_ARC: {                                                                     /* :384-389 */
+                float theta = gm_atan2(px, py) + 3.14159265359f;
+                sdf = (theta < a0) ? sdf : 999.0f;
+                break;
+            }
+            case B_THRESHOLD: sdf = (sdf < a0) ? -1.0f : 1.0f; break;                              /* :390-393 */
+            case B_ONION: sdf = gm_abs(sdf) - a0; break;                                           /* :394-397 */
+            case B_ROUND: sdf = sdf - a0; break;                                                   /* :398-401 */
+
+            /* bridges */
+            case B_GLOW: { float g = apply_glow(sdf, a0); cr = cg = cb = g; ca = 1.0f; break; }    /* :404-408 */
+            case B_SHADE: {                                                                        /* :409-416 */
+                float m = gm_smoothstep(0.005f, -0.005f, sdf);
+                cr = a0 * m; cg = a1 * m; cb = a2 * m; ca = 1.0f;
+                break;
+            }
+            case B_EMISSIVE: { float g = apply_glow(sdf, a0); cr = cg = cb = g; ca = g; break; }   /* :417-421 */
+            case B_PALETTE: {                                                                      /* :422-437, :222-226 */
+                const float* P = PALETTES[S->aux < 8 ? S->aux : 2];
+                float t = gm_clamp(sdf * 0.5f + 0.5f, 0.0f, 1.0f);
+                cr = P[0] + P[3] * gm_cos(6.28318f * (P[6] * t + P[9]));
+                cg = P[1] + P[4] * gm_cos(6.28318f * (P[7] * t + P[10]));
+                cb = P[2] + P[5] * gm_cos(6.28318f * (P[8] * t + P[11]));
+                ca = 1.0f;
+                break;
+            }
+
+            /* colour processors */
+            case B_TINT: cr = cr * a0; cg = cg * a1; cb = cb * a2; ca = 1.0f; break;               /* :440-445 */
+            case B_BLOOM: {                                                                        /* :446-452 */
+                float lum = cr * 0.299f + cg * 0.587f + cb * 0.114f;
+                float add = gm_max(lum - a0, 0.0f) * a1;
+                cr = cr + add; cg = cg + add; cb = cb + add; ca = 1.0f;
+                break;
+            }
+            case B_GRAIN: {                                                                        /* :453-457 */
+                float n = gm_fract(gm_sin(px * 12.9898f + py * 78.233f + time) * 43758.5453f);
+                float add = (n - 0.5f) * a0;
+                cr = cr + add; cg = cg + add; cb = cb + add;
+                break;
+            }
+            case B_VIGNETTE: {                                                                     /* :458-464 */
+                float dist = gm_length2(uvx, uvy);
+                float f = 1.0f - gm_smoothstep(a1, a1 + a0, dist);
+                cr = cr * f; cg = cg * f; cb = cb * f;
+                break;
+            }
+            case B_CHROMATIC: {                                                                    /* :465-472 */
+                float len = gm_length2(uvx, uvy);
+                float dirx = uvx / len * a0;                                                       /* normalize(uv) * offset */
+                float r = cr, b = cb;
+                cr = r * (1.0f + dirx);
+                cb = b * (1.0f - dirx);
+                break;
+            }
+            case B_TONEMAP: {                                                                      /* :473-478 */
+                float r = cr * a0, g = cg * a0, b = cb * a0;
+                cr = r / (r + 1.0f); cg = g / (g + 1.0f); cb = b / (b + 1.0f);
+                break;
+            }
+            case B_SCANLINES: {                                                                    /* :479-484 */
+                float v = gm_sin(uvy * a0 * 3.14159265359f) * a1;
+                float f = 1.0f - v * 0.5f;
+                cr = cr * f; cg = cg * f; cb = cb * f;
+                break;
+            }
+            case B_SATURATE_COLOR: {                                                               /* :485-489 */
+                float lum = cr * 0.299f + cg * 0.587f + cb * 0.114f;
+                cr = gm_mix(lum, cr, a0); cg = gm_mix(lum, cg, a0); cb = gm_mix(lum, cb, a0);
+                break;
+            }
+            case B_GLITCH: {                                                                       /* :490-501 */
+                float gt = gm_floor(time * 10.0f);
+                float n = gm_fract(gm_sin(gt * 43758.5453f + py * 100.0f) * 43758.5453f);
+                float shift = (n - 0.5f) * a0 * 0.1f;
+                float block = gm_step(1.0f - a0 * 0.3f, gm_fract(gm_sin(gt * 12.9898f + gm_floor(py * 20.0f)) * 43758.5453f));
+                cr = cr + shift * block;
+                cb = cb - shift * block;
+                break;
+            }
+            case B_BLEND: cr = cr * a0; cg = cg * a0; cb = cb * a0; break;                         /* :502-505 */
+
+            /* full-screen generators */
+            case B_GRADIENT: { float t = uvy * 0.5f + 0.5f; cr = cg = cb = t; ca = 1.0f; break; }  /* :508-515 */
+            case B_SPECTRUM: {                                                                     /* :516-525 */
+                float sx = uvx * 0.5f + 0.5f;
+                cr = gm_smoothstep(0.0f, 0.33f, sx) * (fc->row[BU_BASS] + a0);
+                cg = gm_smoothstep(0.33f, 0.66f, sx) * (fc->row[BU_MID] + a1);
+                cb = gm_smoothstep(0.66f, 1.0f, sx) * (fc->row[BU_TREBLE] + a2);
+                ca = 1.0f;
+                break;
+            }
+            default: break;
+            }
+            (void)a3;
+        }
+        if (L->end_state != 2) continue;   /* no color_result: the layer contributes nothing */
+        if (L->has_memory) {               /* memory.rs:38-45 */
+            float pr = (float)(prev & 0xffu) / 255.0f, pg = (float)((prev >> 8) & 0xffu) / 255.0f;
+            float pb = (float)((prev >> 16) & 0xffu) / 255.0f, pa = (float)(prev >> 24) / 255.0f;
+            cr = gm_mix(cr, pr, L->decay); cg = gm_mix(cg, pg, L->decay);
+            cb = gm_mix(cb, pb, L->decay); ca = gm_mix(ca, pa, L->decay);
+        }
+        if (multi) {                       /* glsl.rs:251-255 screen blend */
+            fin_r = fin_r + cr - fin_r * cr;
+            fin_g = fin_g + cg - fin_g * cg;
+            fin_b = fin_b + cb - fin_b * cb;
+            fin_a = 1.0f;
+        } else {                           /* glsl.rs:257 */
+            frag[0] = cr; frag[1] = cg; frag[2] = cb; frag[3] = ca;
+        }
+    }
+    if (multi) { out[0] = fin_r; out[1] = fin_g; out[2] = fin_b; out[3] = fin_a; }
+    else { out[0] = frag[0]; out[1] = frag[1]; out[2] = frag[2]; out[3] = frag[3]; }
+}
+
+/* ── frame ─────────────────────────────────────────────────────────────────────────────── */
+typedef struct {
+    const ir_view* ir;
+    frame_consts fc;
+    uint32_t w, h, row_begin, row_end;     /* image rows, top-first */
+    uint32_t band_row0;                    /* first row stored in out/prev */
+    const uint32_t* prev;                  /* previous frame, same band layout, or NULL */
+    uint32_t* out;
+} frame_job;
+
+static void render_rows(const frame_job* J)
+{
+    const float inv_w = 1.0f / (float)J->w, inv_h = 1.0f / (float)J->h;
+    for (uint32_t ty = J->row_begin; ty < J->row_end; ty++) {
+        uint32_t gy = J->h - 1u - ty;                                  /* GL row index, 0 = bottom */
+        float vy = ((float)gy + 0.5f) * inv_h;                         /* v_uv (vertex :541-555, pixel centre) */
+        float uvy = vy * 2.0f - 1.0f;                                  /* glsl.rs:54 */
+        for (uint32_t x = 0; x < J->w; x++) {
+            float vx = ((float)x + 0.5f) * inv_w;
+            float uvx = vx * 2.0f - 1.0f;
+            size_t idx = (size_t)(ty - J->band_row0) * J->w + x;
+            uint32_t prev = J->prev ? J->prev[idx] : 0u;
+            float c[4];
+            shade_pixel(J->ir, &J->fc, uvx, uvy, prev, c);
+            J->out[idx] = pack_unorm8(c[0]) | (pack_unorm8(c[1]) << 8) | (pack_unorm8(c[2]) << 16) | (pack_unorm8(c[3]) << 24);
+        }
+    }
+}
+
+static void* render_thread(void* p) { render_rows((const frame_job*)p); return NULL; }
+
+/* Renders image rows [row0, row0+rows) of one frame. uniforms: one row (10 + n_uniforms floats).
+ * prev/out hold only the band, top row first, RGBA8 (R in the low byte). prev may be NULL (= all
+ * zero). nthreads <= 1 renders on the calling thread. Returns 0, or -1 for a malformed blob. */
+int game_oracle_render(const void* blob, size_t blob_len, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows,
+                       const float* uniforms, const uint8_t* prev_rgba8, uint8_t* out_rgba8, int nthreads)
+{
+    ir_view ir;
+    if (ir_open(blob, blob_len, &ir) != 0 || !uniforms || !out_rgba8 || w == 0 || h == 0 || row0 + rows > h) return -1;
+    frame_consts fc;
+    fc.row = uniforms;
+    fc.aspect = uniforms[BU_RES_X] / uniforms[BU_RES_Y];               /* glsl.rs:55 */
+    fc.time = gm_fract(uniforms[BU_TIME] / 120.0f) * 120.0f;           /* glsl.rs:56 */
+    if (nthreads < 1) nthreads = 1;
+    if ((uint32_t)nthreads > rows) nthreads = (int)(rows ? rows : 1);
+    frame_job* jobs = (frame_job*)calloc((size_t)nthreads, sizeof(frame_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+    if (!jobs || !th) { free(jobs); free(th); return -1; }
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t].ir = &ir; jobs[t].fc = fc; jobs[t].w = w; jobs[t].h = h;
+        jobs[t].row_begin = row0 + (uint32_t)((uint64_t)rows * (uint32_t)t / (uint32_t)nthreads);
+        jobs[t].row_end = row0 + (uint32_t)((uint64_t)rows * (uint32_t)(t + 1) / (uint32_t)nthreads);
+        jobs[t].band_row0 = row0;
+        jobs[t].prev = (const uint32_t*)prev_rgba8;
+        jobs[t].out = (uint32_t*)out_rgba8;
+    }
+    if (nthreads == 1) render_rows(&jobs[0]);
+    else {
+        for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, render_thread, &jobs[t]);
+        for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    }
+    free(jobs); free(th);
+    return 0;
+}
+
+/* ── gravity (gravity.rs:43-120) ───────────────────────────────────────────────────────── */
+enum { LAW_NUM = 0, LAW_DIST, LAW_TIME, LAW_ADD, LAW_SUB, LAW_MUL, LAW_DIV, LAW_POW, LAW_GT, LAW_LT, LAW_NEG,
+       LAW_CALL1, LAW_CALL2, LAW_CALL3 };
+enum { LF_SIN = 0, LF_COS, LF_TAN, LF_ABS, LF_SQRT, LF_EXP, LF_LOG, LF_FLOOR, LF_CEIL, LF_FRACT, LF_SIGN,
+       LF_MIN, LF_MAX, LF_POW, LF_STEP, LF_CLAMP, LF_MIX, LF_SMOOTHSTEP, LF_EXP2, LF_LOG2 };
+
+static float law_call(uint32_t fn, float a, float b, float c)
+{
+    switch (fn) {
+    case LF_SIN: return gm_sin(a); case LF_COS: return gm_cos(a); case LF_TAN: return gm_tan(a);
+    case LF_ABS: return gm_abs(a); case LF_SQRT: return sqrtf(a); case LF_EXP: return gm_exp(a);
+    case LF_LOG: return gm_log(a); case LF_FLOOR: return gm_floor(a); case LF_CEIL: return -gm_floor(-a);
+    case LF_FRACT: return gm_fract(a); case LF_SIGN: return a > 0.0f ? 1.0f : (a < 0.0f ? -1.0f : 0.0f);
+    case LF_EXP2: return gm_exp2(a); case LF_LOG2: return gm_log2(a);
+    case LF_MIN: return gm_min(a, b); case LF_MAX: return gm_max(a, b); case LF_POW: return gm_pow(a, b);
+    case LF_STEP: return gm_step(a, b);
+    case LF_CLAMP: return gm_clamp(a, b, c); case LF_MIX: return gm_mix(a, b, c);
+    case LF_SMOOTHSTEP: return gm_smoothstep(a, b, c);
+    default: return 0.0f;
+    }
+}
+
+static float eval_law(const ir_law* law, uint32_t n, float dist, float time)   /* gravity.rs:10-41 */
+{
+    float st[64];
+    int sp = 0;
+    if (n == 0) return 1.0f;
+    for (uint32_t i = 0; i < n; i++) {
+        const ir_law* o = &law[i];
+        switch (o->op) {
+        case LAW_NUM: st[sp++] = o->val; break;
+        case LAW_DIST: st[sp++] = dist; break;
+        case LAW_TIME: st[sp++] = time; break;
+        case LAW_ADD: sp--; st[sp - 1] = st[sp - 1] + st[sp]; break;
+        case LAW_SUB: sp--; st[sp - 1] = st[sp - 1] - st[sp]; break;
+        case LAW_MUL: sp--; st[sp - 1] = st[sp - 1] * st[sp]; break;
+        case LAW_DIV: sp--; st[sp - 1] = st[sp - 1] / st[sp]; break;
+        case LAW_POW: sp--; st[sp - 1] = gm_pow(st[sp - 1], st[sp]); break;
+        case LAW_GT: sp--; st[sp - 1] = st[sp - 1] > st[sp] ? 1.0f : 0.0f; break;
+        case LAW_LT: sp--; st[sp - 1] = st[sp - 1] < st[sp] ? 1.0f : 0.0f; break;
+        case LAW_NEG: st[sp - 1] = -st[sp - 1]; break;
+        case LAW_CALL1: st[sp - 1] = law_call(o->fn, st[sp - 1], 0.0f, 0.0f); break;
+        case LAW_CALL2: sp--; st[sp - 1] = law_call(o->fn, st[sp - 1], st[sp], 0.0f); break;
+        case LAW_CALL3: sp -= 2; st[sp - 1] = law_call(o->fn, st[sp - 1], st[sp], st[sp + 1]); break;
+        default: break;
+        }
+        if (sp >= 60) return 0.0f;
+    }
+    return st[0];
+}
+
+typedef struct {
+    const ir_view* ir;
+    const float* in;   /* n x {pos.x, pos.y, vel.x, vel.y} */
+    float* out;
+    uint32_t n, begin, end;
+    float dt, time;
+} grav_job;
+
+static void gravity_range(const grav_job* J)
+{
+    const ir_view* ir = J->ir;
+    for (uint32_t idx = J->begin; idx < J->end; idx++) {
+        float sx = J->in[4 * idx], sy = J->in[4 * idx + 1];
+        float fx = 0.0f, fy = 0.0f;
+        for (uint32_t j = 0; j < J->n; j++) {                                   /* gravity.rs:78-89 */
+            if (j == idx) continue;
+            float dx = J->in[4 * j] - sx, dy = J->in[4 * j + 1] - sy;
+            float dist = gm_max(gm_length2(dx, dy), 0.001f);
+            float dirx = dx / dist, diry = dy / dist;
+            float f = eval_law(ir->law, ir->h->n_law, dist, J->time);
+            fx = fx + dirx * f; fy = fy + diry * f;
+        }
+        float vx = J->in[4 * idx + 2] * ir->h->damping + fx * J->dt;            /* gravity.rs:92-96 */
+        float vy = J->in[4 * idx + 3] * ir->h->damping + fy * J->dt;
+        float px = sx + vx * J->dt, py = sy + vy * J->dt;
+        if (ir->h->bounds == 0) {                                               /* reflect :100-106 */
+            if (px < -1.0f) { px = -1.0f; vx = -vx; }
+            if (px > 1.0f) { px = 1.0f; vx = -vx; }
+            if (py < -1.0f) { py = -1.0f; vy = -vy; }
+            if (py > 1.0f) { py = 1.0f; vy = -vy; }
+        } else if (ir->h->bounds == 1) {                                        /* wrap :107-110 */
+            px = gm_fract((px + 1.0f) * 0.5f) * 2.0f - 1.0f;
+            py = gm_fract((py + 1.0f) * 0.5f) * 2.0f - 1.0f;
+        }
+        J->out[4 * idx] = px; J->out[4 * idx + 1] = py; J->out[4 * idx + 2] = vx; J->out[4 * idx + 3] = vy;
+    }
+}
+static void* gravity_thread(void* p) { gravity_range((const grav_job*)p); return NULL; }
+
+/* Advances `steps` steps of dt. particles: n x {pos.x, pos.y, vel.x, vel.y}, updated in place.
+ * *sim_time is the dispatch clock (`_time += dt` before each step, gravity.rs:158). */
+int game_oracle_gravity(const void* blob, size_t blob_len, uint32_t n, float* particles, float dt, uint32_t steps,
+                        float* sim_time, int nthreads)
+{
+    ir_view ir;
+    if (ir_open(blob, blob_len, &ir) != 0 || !ir.h->gravity_present || !particles || !sim_time) return -1;
+    float* tmp = (float*)malloc((size_t)n * 16);
+    if (!tmp) return -1;
+    if (nthreads < 1) nthreads = 1;
+    if ((uint32_t)nthreads > n) nthreads = n ? (int)n : 1;
+    grav_job* jobs = (grav_job*)calloc((size_t)nthreads, sizeof(grav_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+    float* a = particles;
+    float* b = tmp;
+    for (uint32_t s = 0; s < steps; s++) {
+        *sim_time = *sim_time + dt;
+        for (int t = 0; t < nthreads; t++) {
+            jobs[t].ir = &ir; jobs[t].in = a; jobs[t].out = b; jobs[t].n = n; jobs[t].dt = dt; jobs[t].time = *sim_time;
+            jobs[t].begin = (uint32_t)((uint64_t)n * (uint32_t)t / (uint32_t)nthreads);
+            jobs[t].end = (uint32_t)((uint64_t)n * (uint32_t)(t + 1) / (uint32_t)nthreads);
+        }
+        if (nthreads == 1) gravity_range(&jobs[0]);
+        else {
+            for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, gravity_thread, &jobs[t]);
+            for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+        }
+        float* sw = a; a = b; b = sw;
+    }
+    if (a != particles) memcpy(particles, a, (size_t)n * 16);
+    free(tmp); free(jobs); free(th);
+    return 0;
+}
+
+/* SplitMix64 particle initialisation used by the synthetic particle workloads:
+ * pos = (u >> 40) * 2^-23 - 1 per coordinate, vel = 0. */
+void game_oracle_seed_particles(uint32_t n, uint64_t seed, float* particles)
+{
+    uint64_t s = seed;
+    for (uint32_t i = 0; i < n; i++) {
+        for (int k = 0; k < 2; k++) {
+            s += 0x9E3779B97F4A7C15ull;
+            uint64_t z = s;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z = z ^ (z >> 31);
+            particles[4 * i + k] = (float)(z >> 40) * 0x1p-23f - 1.0f;
+        }
+        particles[4 * i + 2] = 0.0f;
+        particles[4 * i + 3] = 0.0f;
+    }
+}
+
+/* Exposed for unit tests of the math layer. */
+float game_oracle_sin(float x) { return gm_sin(x); }
+float game_oracle_cos(float x) { return gm_cos(x); }
+float game_oracle_atan2(float y, float x) { return gm_atan2(y, x); }
+float game_oracle_fract(float x) { return gm_fract(x); }
+float game_oracle_hash2(float x, float y) { return hash2(x, y); }
+float game_oracle_noise2(float x, float y) { return noise2(x, y); }
+float game_oracle_fbm2(float x, float y, int oct, float pers, float lac) { return fbm2(x, y, oct, pers, lac); }
+float game_oracle_simplex2d(float x, float y) { return simplex2d(x, y); }
+float game_oracle_voronoi2d(float x, float y, float s) { return voronoi2d(x, y, s); }
+float game_oracle_pow(float x, float y) { return gm_pow(x, y); }
+float game_oracle_exp(float x) { return gm_exp(x); }
+float game_oracle_log(float x) { return gm_log(x); }
