@@ -1,0 +1,335 @@
+"""ctypes binding of libgame_hip.so (C ABI: include/game_hip.h).
+
+Thin host-side mirror of the reference's public API (game-compiler/src/lib.rs: compile, check, lex,
+list_builtins) plus the GPU render path that replaces its browser runtime. Nothing here computes
+pixels: every call goes to the shared library, and a missing library or a missing GPU raises.
+"""
+import ctypes
+import json
+import os
+import struct
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgame_hip.so")
+
+BU_COUNT = 10  # built-in floats per frame row: time, 5 audio, res.xy, mouse.xy (runtime/helpers.rs:222-232)
+BU_TIME, BU_BASS, BU_MID, BU_TREBLE, BU_ENERGY, BU_BEAT, BU_RES_X, BU_RES_Y, BU_MOUSE_X, BU_MOUSE_Y = range(10)
+
+
+class GameError(RuntimeError):
+    """A non-zero return from the library; .code is the GAME_E_* / E00x value."""
+
+    def __init__(self, code, message, rendered=""):
+        super().__init__(message)
+        self.code = code
+        self.rendered = rendered
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C game-engine_amd` (or __graft_entry__.build())")
+    lib = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, sz, u32, u64, f32 = c.c_void_p, c.c_size_t, c.c_uint32, c.c_uint64, c.c_float
+    sig = {
+        "game_last_error": (c.c_char_p, []),
+        "game_last_error_rendered": (c.c_char_p, []),
+        "game_front_compile": (c.c_int, [c.c_char_p, sz, c.POINTER(vp)]),
+        "game_program_free": (None, [vp]),
+        "game_program_cinematic_count": (sz, [vp]),
+        "game_program_ir": (vp, [vp, sz]),
+        "game_program_warning_count": (sz, [vp]),
+        "game_program_warning": (c.c_char_p, [vp, sz]),
+        "game_front_lex": (c.c_int, [c.c_char_p, sz, c.POINTER(sz), vp, sz]),
+        "game_builtin_count": (sz, []),
+        "game_builtin_describe": (c.c_char_p, [sz]),
+        "game_ir_name": (c.c_char_p, [vp]),
+        "game_ir_json": (c.c_char_p, [vp]),
+        "game_ir_blob": (sz, [vp, c.POINTER(vp)]),
+        "game_ir_uniform_count": (u32, [vp]),
+        "game_ir_uniform_name": (c.c_char_p, [vp, u32]),
+        "game_ir_uniform_default": (c.c_double, [vp, u32]),
+        "game_ir_flags": (u32, [vp]),
+        "game_ir_uses_memory": (c.c_int, [vp]),
+        "game_ir_has_gravity": (c.c_int, [vp]),
+        "game_ir_frame_floats": (u32, [vp]),
+        "game_ir_default_uniforms": (None, [vp, f32, u32, u32, vp]),
+        "game_hip_device_count": (c.c_int, [c.POINTER(c.c_int)]),
+        "game_hip_create": (c.c_int, [vp, u32, u32, c.c_int, c.POINTER(vp)]),
+        "game_hip_destroy": (None, [vp]),
+        "game_hip_set_ring": (c.c_int, [vp, u32]),
+        "game_hip_render": (c.c_int, [vp, vp, u32, vp]),
+        "game_hip_render_band": (c.c_int, [vp, vp, u32, u32, u32, vp]),
+        "game_hip_reset_memory": (c.c_int, [vp]),
+        "game_hip_sync": (c.c_int, [vp]),
+        "game_hip_frame_ptr": (vp, [vp, u32]),
+        "game_hip_ring_frames": (u32, [vp]),
+        "game_hip_last_kernel_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(u32)]),
+        "game_hip_kernel_source": (c.c_char_p, [vp]),
+        "game_hip_compile_only": (c.c_int, [vp, c.POINTER(sz)]),
+        "game_hip_particles_init": (c.c_int, [vp, u32, vp, vp]),
+        "game_hip_particles_seed": (c.c_int, [vp, u32, u64]),
+        "game_hip_particles_step": (c.c_int, [vp, f32, u32, u32, u32]),
+        "game_hip_particles_read": (c.c_int, [vp, vp, vp]),
+        "game_hip_particles_positions": (c.c_int, [vp, c.POINTER(vp), c.POINTER(vp)]),
+        "game_hip_particles_time": (c.c_int, [vp, c.POINTER(f32)]),
+        "game_hip_eval": (c.c_int, [c.c_int, u32, vp, vp, vp]),
+        "game_hip_check_exhaustive": (c.c_int, [c.c_int, c.POINTER(u64), c.POINTER(u32)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)   # AttributeError here == a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sorted(sig)
+
+
+lib, EXPORTED_SYMBOLS = _load()
+
+
+def _check(rc):
+    if rc != 0:
+        raise GameError(rc, lib.game_last_error().decode("utf-8", "replace"),
+                        lib.game_last_error_rendered().decode("utf-8", "replace"))
+
+
+class Cinematic:
+    """One cinematic's resolved IR (reference: codegen::ShaderOutput, game-compiler/src/codegen/mod.rs:35-48)."""
+
+    def __init__(self, program, handle):
+        self._program = program   # keeps the owning program alive
+        self._h = handle
+
+    @property
+    def name(self):
+        return lib.game_ir_name(self._h).decode()
+
+    @property
+    def ir(self):
+        return json.loads(lib.game_ir_json(self._h).decode())
+
+    @property
+    def blob(self):
+        p = ctypes.c_void_p()
+        n = lib.game_ir_blob(self._h, ctypes.byref(p))
+        return ctypes.string_at(p, n)
+
+    @property
+    def uniforms(self):
+        n = lib.game_ir_uniform_count(self._h)
+        return [(lib.game_ir_uniform_name(self._h, i).decode(), lib.game_ir_uniform_default(self._h, i)) for i in range(n)]
+
+    @property
+    def flags(self):
+        return lib.game_ir_flags(self._h)
+
+    @property
+    def uses_memory(self):
+        return bool(lib.game_ir_uses_memory(self._h))
+
+    @property
+    def has_gravity(self):
+        return bool(lib.game_ir_has_gravity(self._h))
+
+    @property
+    def frame_floats(self):
+        return lib.game_ir_frame_floats(self._h)
+
+    def uniform_rows(self, times, w, h, audio=None, user=None):
+        """Frame uniform table: one row per entry of `times` (seconds), reference defaults elsewhere."""
+        times = np.asarray(times, dtype=np.float32).reshape(-1)
+        rows = np.zeros((len(times), self.frame_floats), dtype=np.float32)
+        for k, t in enumerate(times):
+            lib.game_ir_default_uniforms(self._h, float(t), w, h, rows[k].ctypes.data)
+        if audio:
+            for key, col in (("bass", BU_BASS), ("mid", BU_MID), ("treble", BU_TREBLE), ("energy", BU_ENERGY), ("beat", BU_BEAT)):
+                if key in audio:
+                    rows[:, col] = np.asarray(audio[key], dtype=np.float32)
+        if user:
+            names = [n for n, _ in self.uniforms]
+            for key, val in user.items():
+                rows[:, BU_COUNT + names.index(key)] = np.asarray(val, dtype=np.float32)
+        return rows
+
+    def compile_only(self):
+        """hiprtc-compiles the generated kernels for gfx950 without a device; returns code bytes."""
+        n = ctypes.c_size_t()
+        _check(lib.game_hip_compile_only(self._h, ctypes.byref(n)))
+        return n.value
+
+    def renderer(self, w, h, device=0):
+        return Renderer(self, w, h, device)
+
+
+class Program:
+    """Result of compiling .game source (reference: game_compiler::compile, game-compiler/src/lib.rs:117)."""
+
+    def __init__(self, source):
+        if isinstance(source, str):
+            source = source.encode("utf-8")
+        h = ctypes.c_void_p()
+        _check(lib.game_front_compile(source, len(source), ctypes.byref(h)))
+        self._h = h
+        n = lib.game_program_cinematic_count(h)
+        self.cinematics = [Cinematic(self, lib.game_program_ir(h, i)) for i in range(n)]
+        self.warnings = [lib.game_program_warning(h, i).decode() for i in range(lib.game_program_warning_count(h))]
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.game_program_free(h)
+            self._h = None
+
+
+def compile(source):
+    return Program(source)
+
+
+def lex(source):
+    """Token spans (start, end) of `source` (reference: game_compiler::lex)."""
+    if isinstance(source, str):
+        source = source.encode("utf-8")
+    n = ctypes.c_size_t()
+    _check(lib.game_front_lex(source, len(source), ctypes.byref(n), None, 0))
+    spans = (ctypes.c_size_t * (2 * max(n.value, 1)))()
+    _check(lib.game_front_lex(source, len(source), ctypes.byref(n), spans, n.value))
+    return [(spans[2 * i], spans[2 * i + 1]) for i in range(n.value)]
+
+
+def list_builtins():
+    out = []
+    for i in range(lib.game_builtin_count()):
+        name, inp, outp, params = lib.game_builtin_describe(i).decode().split("|")
+        out.append({"name": name, "input": inp, "output": outp, "params": [p for p in params.split(",") if p]})
+    return out
+
+
+def device_count():
+    n = ctypes.c_int()
+    _check(lib.game_hip_device_count(ctypes.byref(n)))
+    return n.value
+
+
+class Renderer:
+    """GPU context for one cinematic at one resolution (reference: GameRendererGL, runtime/helpers.rs:131-241)."""
+
+    def __init__(self, cinematic, w, h, device=0):
+        self.cinematic = cinematic
+        self.w, self.h = w, h
+        h_ = ctypes.c_void_p()
+        _check(lib.game_hip_create(cinematic._h, w, h, device, ctypes.byref(h_)))
+        self._h = h_
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.game_hip_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_ring(self, frames):
+        _check(lib.game_hip_set_ring(self._h, frames))
+
+    @property
+    def ring_frames(self):
+        return lib.game_hip_ring_frames(self._h)
+
+    def _rows(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim == 1:
+            rows = rows[None, :]
+        if rows.shape[1] != self.cinematic.frame_floats:
+            raise ValueError(f"uniform rows need {self.cinematic.frame_floats} floats, got {rows.shape[1]}")
+        return rows
+
+    def render(self, rows, readback=True):
+        """Renders len(rows) frames; returns (nframes, h, w, 4) uint8 (top row first) or None."""
+        rows = self._rows(rows)
+        out = np.empty((rows.shape[0], self.h, self.w, 4), dtype=np.uint8) if readback else None
+        _check(lib.game_hip_render(self._h, rows.ctypes.data, rows.shape[0], out.ctypes.data if readback else None))
+        return out
+
+    def render_band(self, rows, row0, nrows, readback=True):
+        rows = self._rows(rows)
+        out = np.empty((rows.shape[0], nrows, self.w, 4), dtype=np.uint8) if readback else None
+        _check(lib.game_hip_render_band(self._h, rows.ctypes.data, rows.shape[0], row0, nrows,
+                                        out.ctypes.data if readback else None))
+        return out
+
+    def reset_memory(self):
+        _check(lib.game_hip_reset_memory(self._h))
+
+    def sync(self):
+        _check(lib.game_hip_sync(self._h))
+
+    def last_kernel_ms(self):
+        ms, n = ctypes.c_float(), ctypes.c_uint32()
+        _check(lib.game_hip_last_kernel_ms(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def frame_ptr(self, slot):
+        return lib.game_hip_frame_ptr(self._h, slot)
+
+    @property
+    def kernel_source(self):
+        return lib.game_hip_kernel_source(self._h).decode()
+
+    # particles (reference: GameGravitySim, game-compiler/src/codegen/gravity.rs:123-191)
+    def particles_init(self, pos_xy, vel_xy=None):
+        pos = np.ascontiguousarray(pos_xy, dtype=np.float32).reshape(-1, 2)
+        vel = None if vel_xy is None else np.ascontiguousarray(vel_xy, dtype=np.float32).reshape(-1, 2)
+        _check(lib.game_hip_particles_init(self._h, pos.shape[0], pos.ctypes.data, None if vel is None else vel.ctypes.data))
+        self._n = pos.shape[0]
+
+    def particles_seed(self, n, seed=0x9E3779B97F4A7C15):
+        _check(lib.game_hip_particles_seed(self._h, n, seed))
+        self._n = n
+
+    def particles_step(self, dt, steps=1, first=0, count=None):
+        _check(lib.game_hip_particles_step(self._h, dt, steps, first, self._n if count is None else count))
+
+    def particles_read(self):
+        pos = np.empty((self._n, 2), dtype=np.float32)
+        vel = np.empty((self._n, 2), dtype=np.float32)
+        _check(lib.game_hip_particles_read(self._h, pos.ctypes.data, vel.ctypes.data))
+        return pos, vel
+
+    def particles_positions(self):
+        x, y = ctypes.c_void_p(), ctypes.c_void_p()
+        _check(lib.game_hip_particles_positions(self._h, ctypes.byref(x), ctypes.byref(y)))
+        return x.value, y.value
+
+    def particles_time(self):
+        t = ctypes.c_float()
+        _check(lib.game_hip_particles_time(self._h, ctypes.byref(t)))
+        return t.value
+
+
+EVAL_OPS = {"fract": 0, "sin": 1, "cos": 2, "atan2": 3, "hash2": 4, "noise2": 5, "simplex2d": 6, "voronoi2d": 7,
+            "exp2": 8, "log2": 9, "pow": 10, "max": 11, "min": 12, "fbm6": 13, "sqrt": 14, "div": 15,
+            "smoothstep_glow": 16, "mod": 17}
+
+
+def device_eval(op, a, b=None):
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+    bb = None if b is None else np.ascontiguousarray(b, dtype=np.float32).reshape(-1)
+    out = np.empty_like(a)
+    _check(lib.game_hip_eval(EVAL_OPS[op], a.size, a.ctypes.data, None if bb is None else bb.ctypes.data, out.ctypes.data))
+    return out
+
+
+def check_exhaustive(which):
+    m, f = ctypes.c_uint64(), ctypes.c_uint32()
+    _check(lib.game_hip_check_exhaustive(which, ctypes.byref(m), ctypes.byref(f)))
+    return m.value, f.value
+
+
+def parse_blob(blob):
+    """Decodes the flat IR blob (layout in include/game_hip.h) into a dict; used by tests."""
+    hdr = struct.unpack_from("<10IfI64s", blob, 0)
+    keys = ("magic", "total", "n_layers", "n_stages", "n_uniforms", "n_law", "flags", "multi_layer", "uses_memory",
+            "gravity_present", "damping", "bounds", "name")
+    out = dict(zip(keys, hdr))
+    out["name"] = out["name"].split(b"\0")[0].decode()
+    return out

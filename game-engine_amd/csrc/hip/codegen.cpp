@@ -1,0 +1,275 @@
+// Kernel generator: flat IR -> HIP source of one fused per-pixel kernel (and, for cinematics
+// with a gravity block, one all-pairs particle kernel). This is the back end that takes the place
+// of the reference's GLSL/WGSL emitters (game-compiler/src/codegen/glsl.rs:20-80, :228-259 for
+// the fragment program; game-compiler/src/codegen/gravity.rs:43-120 for the compute program).
+// The generated text only sequences calls into game_device.h with the stage arguments baked in.
+#include "codegen.hpp"
+#include <cstdio>
+#include <cmath>
+#include <cstring>
+
+namespace game {
+
+std::string float_literal(float v)
+{
+    if (v != v) return "__builtin_nanf(\"\")";
+    if (v == INFINITY) return "__builtin_inff()";
+    if (v == -INFINITY) return "(-__builtin_inff())";
+    char buf[64];
+    snprintf(buf, sizeof buf, "%af", (double)v);   // hex float: exact
+    return buf;
+}
+
+namespace {
+
+// Frame-row layout used by the kernels: the caller's 10 + n floats, then two derived values the
+// host computes once per frame (glsl.rs:55-56).
+std::string arg_expr(const IrArg& a)
+{
+    switch (a.kind) {
+    case ARG_LIT: return float_literal(a.lit);
+    case ARG_USER: return "U[" + std::to_string(BU_COUNT + a.slot) + "]";
+    default: return a.slot == BU_TIME ? std::string("s.time") : "U[" + std::to_string(a.slot) + "]";
+    }
+}
+
+int octaves_of(float o)
+{
+    if (!(o >= 1.0f)) return 0;
+    if (o >= 32.0f) return 32;
+    return (int)o;
+}
+
+const float PALETTES[8][12] = {   // glsl.rs:424-434
+    {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 1.0f, 1.0f, 1.0f, 0.00f, 0.10f, 0.20f},
+    {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 1.0f, 1.0f, 1.0f, 0.30f, 0.20f, 0.20f},
+    {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 1.0f, 1.0f, 1.0f, 0.00f, 0.33f, 0.67f},
+    {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 1.0f, 0.7f, 0.4f, 0.00f, 0.15f, 0.20f},
+    {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 1.0f, 1.0f, 0.5f, 0.80f, 0.90f, 0.30f},
+    {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 2.0f, 1.0f, 0.0f, 0.50f, 0.20f, 0.25f},
+    {0.8f, 0.5f, 0.4f, 0.2f, 0.4f, 0.2f, 2.0f, 1.0f, 1.0f, 0.00f, 0.25f, 0.25f},
+    {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 1.0f, 1.0f, 1.0f, 0.00f, 0.10f, 0.20f},
+};
+
+std::string stage_call(const IrStage& st)
+{
+    auto A = [&](int i) { return arg_expr(st.args[i]); };
+    auto call = [&](const char* fn, int n) {
+        std::string c = std::string(fn) + "(s";
+        for (int i = 0; i < n; ++i) c += ", " + A(i);
+        return c + ");";
+    };
+    switch (st.builtin) {
+    case B_CIRCLE: return call("gb_circle", 1);
+    case B_RING: return call("gb_ring", 2);
+    case B_STAR: return call("gb_star", 3);
+    case B_BOX: return call("gb_box", 2);
+    case B_POLYGON: return call("gb_polygon", 2);
+    case B_SIMPLEX: return call("gb_simplex", 1);
+    case B_VORONOI: return call("gb_voronoi", 1);
+    case B_CONCENTRIC_WAVES: return call("gb_concentric_waves", 3);
+    case B_FBM: {
+        std::string oct = st.args[1].kind == ARG_LIT ? std::to_string(octaves_of(st.args[1].lit)) : "gd_octaves(" + A(1) + ")";
+        return "gb_fbm(s, " + A(0) + ", " + oct + ", " + A(2) + ", " + A(3) + ");";
+    }
+    case B_ROTATE: return call("gb_rotate", 1);
+    case B_TRANSLATE: return call("gb_translate", 2);
+    case B_SCALE: return call("gb_scale", 1);
+    case B_TWIST: return call("gb_twist", 1);
+    case B_MIRROR: return call("gb_mirror", 1);
+    case B_REPEAT: return call("gb_repeat", 1);
+    case B_DOMAIN_WARP: return call("gb_domain_warp", 2);
+    case B_CURL_NOISE: return call("gb_curl_noise", 2);
+    case B_DISPLACE: return call("gb_displace", 1);
+    case B_MASK_ARC: return call("gb_mask_arc", 1);
+    case B_THRESHOLD: return call("gb_threshold", 1);
+    case B_ONION: return call("gb_onion", 1);
+    case B_ROUND: return call("gb_round", 1);
+    case B_GLOW: return call("gb_glow", 1);
+    case B_SHADE: return call("gb_shade", 3);
+    case B_EMISSIVE: return call("gb_emissive", 1);
+    case B_PALETTE: {
+        const float* P = PALETTES[st.aux < 8 ? st.aux : 2];
+        std::string c = "gb_palette(s";
+        for (int i = 0; i < 12; ++i) c += ", " + float_literal(P[i]);
+        return c + ");";
+    }
+    case B_TINT: return call("gb_tint", 3);
+    case B_BLOOM: return call("gb_bloom", 2);
+    case B_GRAIN: return call("gb_grain", 1);
+    case B_VIGNETTE: return call("gb_vignette", 2);
+    case B_CHROMATIC: return call("gb_chromatic", 1);
+    case B_TONEMAP: return call("gb_tonemap", 1);
+    case B_SCANLINES: return call("gb_scanlines", 2);
+    case B_SATURATE_COLOR: return call("gb_saturate_color", 1);
+    case B_GLITCH: return call("gb_glitch", 1);
+    case B_BLEND: return call("gb_blend", 1);
+    case B_GRADIENT: return "gb_gradient(s);";
+    case B_SPECTRUM: return call("gb_spectrum", 3);
+    default: return "/* unknown builtin */";
+    }
+}
+
+}  // namespace
+
+std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
+{
+    std::string k;
+    k.reserve(8192);
+    k += "// generated for cinematic \"" + ir.name + "\"\n";
+    k += "#include \"game_device.h\"\n\n";
+    k += "struct GameFrameParams {\n"
+         "    gd_u32* out;\n"
+         "    const gd_u32* prev;\n"
+         "    const float* utab;\n"
+         "    unsigned long long frame_pixels;\n"
+         "    gd_u32 w, h, row0, rows;\n"
+         "    gd_u32 ustride, slot0, ring, frame0;\n"
+         "    float inv_w, inv_h;\n"
+         "};\n\n";
+    k += "extern \"C\" __global__ __launch_bounds__(256) void game_frame(GameFrameParams P)\n{\n";
+    // wave64 tile = 8x8 pixels; a 256-thread workgroup covers 32x8 (4 waves side by side)
+    k += "    const gd_u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;\n";
+    k += "    const gd_u32 x0 = (blockIdx.x * 32u + wave * 8u + (lane & 7u)) * " + std::to_string(shape.pixels_per_lane) + "u;\n";
+    k += "    const gd_u32 ty = P.row0 + blockIdx.y * 8u + (lane >> 3);\n";
+    k += "    if (ty >= P.row0 + P.rows) return;\n";
+    k += "    const gd_u32 fidx = blockIdx.z;\n";
+    k += "    const float* __restrict__ U = P.utab + (unsigned long long)(P.frame0 + fidx) * P.ustride;\n";
+    k += "    const gd_u32 slot = (P.slot0 + fidx) % P.ring;\n";
+    k += "    gd_u32* __restrict__ dst = P.out + (unsigned long long)slot * P.frame_pixels + (unsigned long long)ty * P.w;\n";
+    k += "    GdPix s;\n";
+    k += "    s.time = U[" + std::to_string(shape.time_slot) + "];\n";
+    k += "    const float aspect = U[" + std::to_string(shape.aspect_slot) + "];\n";
+    k += "    s.bass = U[1]; s.mid = U[2]; s.treble = U[3];\n";
+    k += "    const float vy = ((float)(P.h - 1u - ty) + 0.5f) * P.inv_h;\n";   // GL row 0 is the bottom row
+    k += "    s.uvy = vy * 2.0f - 1.0f;\n";
+    if (shape.pixels_per_lane > 1) k += "#pragma unroll 1\n    for (gd_u32 kx = 0; kx < " + std::to_string(shape.pixels_per_lane) + "u; ++kx) {\n    const gd_u32 x = x0 + kx;\n";
+    else k += "    {\n    const gd_u32 x = x0;\n";
+    k += "    if (x < P.w) {\n";
+    k += "    const float vx = ((float)x + 0.5f) * P.inv_w;\n";
+    k += "    s.uvx = vx * 2.0f - 1.0f;\n";
+    if (ir.uses_memory)
+        k += "    const gd_u32 prev = P.prev ? P.prev[(unsigned long long)ty * P.w + x] : 0u;\n";
+    if (ir.multi_layer) k += "    float fr = 0.0f, fg = 0.0f, fb = 0.0f, fa = 1.0f;\n";
+    else k += "    float fr = 0.0f, fg = 0.0f, fb = 0.0f, fa = 1.0f;\n";
+    for (size_t li = 0; li < ir.layers.size(); ++li) {
+        const IrLayer& L = ir.layers[li];
+        if (!L.is_pipeline || L.end_state != State::Color) continue;
+        k += "    {   // layer " + std::to_string(li) + "\n";
+        k += "        s.px = s.uvx * aspect; s.py = s.uvy; s.sdf = 0.0f; s.r = s.g = s.b = s.a = 0.0f;\n";
+        for (uint32_t si = 0; si < L.stage_count; ++si)
+            k += "        " + stage_call(ir.stages[L.stage_begin + si]) + "\n";
+        if (L.has_memory) k += "        gb_memory_mix(s, prev, " + float_literal(L.decay) + ");\n";
+        if (ir.multi_layer) {
+            k += "        fr = fr + s.r - fr * s.r; fg = fg + s.g - fg * s.g; fb = fb + s.b - fb * s.b; fa = 1.0f;\n";
+        } else {
+            k += "        fr = s.r; fg = s.g; fb = s.b; fa = s.a;\n";
+        }
+        k += "    }\n";
+    }
+    k += "    dst[x] = gd_pack_rgba8(fr, fg, fb, fa);\n";
+    k += "    }\n    }\n";
+    k += "}\n";
+    return k;
+}
+
+// ── gravity ──────────────────────────────────────────────────────────────────────────────
+namespace {
+
+std::string law_expr(const Ir& ir)
+{
+    static const char* fn1[] = {"gd_sin", "gd_cos", "gd_tan", "gd_abs", "gd_sqrt", "gd_exp", "gd_log", "gd_floor", "gd_ceil",
+                                "gd_fract", "gd_sign", "", "", "", "", "", "", "", "gd_exp2", "gd_log2"};
+    std::vector<std::string> st;
+    if (ir.gravity.law.empty()) return "1.0f";
+    for (const IrLawOp& o : ir.gravity.law) {
+        auto pop = [&]() { std::string t = st.back(); st.pop_back(); return t; };
+        switch (o.op) {
+        case LAW_NUM: st.push_back(float_literal(o.val)); break;
+        case LAW_DIST: st.push_back("dist"); break;
+        case LAW_TIME: st.push_back("P.time"); break;
+        case LAW_ADD: { auto r = pop(), l = pop(); st.push_back("(" + l + " + " + r + ")"); break; }
+        case LAW_SUB: { auto r = pop(), l = pop(); st.push_back("(" + l + " - " + r + ")"); break; }
+        case LAW_MUL: { auto r = pop(), l = pop(); st.push_back("(" + l + " * " + r + ")"); break; }
+        case LAW_DIV: { auto r = pop(), l = pop(); st.push_back("(" + l + " / " + r + ")"); break; }
+        case LAW_POW: { auto r = pop(), l = pop(); st.push_back("gd_pow(" + l + ", " + r + ")"); break; }
+        case LAW_GT: { auto r = pop(), l = pop(); st.push_back("((" + l + " > " + r + ") ? 1.0f : 0.0f)"); break; }
+        case LAW_LT: { auto r = pop(), l = pop(); st.push_back("((" + l + " < " + r + ") ? 1.0f : 0.0f)"); break; }
+        case LAW_NEG: { auto v = pop(); st.push_back("(-" + v + ")"); break; }
+        case LAW_CALL1: { auto v = pop(); st.push_back(std::string(fn1[o.fn]) + "(" + v + ")"); break; }
+        case LAW_CALL2: {
+            auto b = pop(), a = pop();
+            const char* f = o.fn == LF_MIN ? "gd_min" : o.fn == LF_MAX ? "gd_max" : o.fn == LF_POW ? "gd_pow" : "gd_step";
+            st.push_back(std::string(f) + "(" + a + ", " + b + ")");
+            break;
+        }
+        case LAW_CALL3: {
+            auto c = pop(), b = pop(), a = pop();
+            const char* f = o.fn == LF_CLAMP ? "gd_clamp" : o.fn == LF_MIX ? "gd_mix" : "gd_smoothstep";
+            st.push_back(std::string(f) + "(" + a + ", " + b + ", " + c + ")");
+            break;
+        }
+        default: break;
+        }
+    }
+    return st.empty() ? "1.0f" : st.back();
+}
+
+}  // namespace
+
+std::string generate_gravity_kernel(const Ir& ir)
+{
+    std::string k;
+    k += "// generated gravity step for cinematic \"" + ir.name + "\"\n";
+    k += "#include \"game_device.h\"\n\n";
+    k += "GD float gd_ceil(float x) { return -gd_floor(-x); }\n";
+    k += "GD float gd_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }\n\n";
+    k += "struct GameGravityParams {\n"
+         "    const float* xin; const float* yin;\n"
+         "    float* xout; float* yout; float* vx; float* vy;\n"
+         "    gd_u32 n, first, count, pad;\n"
+         "    float dt, time;\n"
+         "};\n\n";
+    // One particle per lane; positions of all n particles stream through LDS in tiles of 256 and
+    // every lane walks j = 0..n-1 in index order (the summation order of the sequential loop).
+    k += "extern \"C\" __global__ __launch_bounds__(256) void game_gravity(GameGravityParams P)\n{\n";
+    k += "    __shared__ float tx[256];\n    __shared__ float ty[256];\n";
+    k += "    const gd_u32 local = blockIdx.x * 256u + threadIdx.x;\n";
+    k += "    const bool live = local < P.count;\n";
+    k += "    const gd_u32 idx = P.first + (live ? local : 0u);\n";
+    k += "    const float sx = P.xin[idx], sy = P.yin[idx];\n";
+    k += "    float fx = 0.0f, fy = 0.0f;\n";
+    k += "    for (gd_u32 base = 0; base < P.n; base += 256u) {\n";
+    k += "        const gd_u32 j0 = base + threadIdx.x;\n";
+    k += "        tx[threadIdx.x] = j0 < P.n ? P.xin[j0] : 0.0f;\n";
+    k += "        ty[threadIdx.x] = j0 < P.n ? P.yin[j0] : 0.0f;\n";
+    k += "        __syncthreads();\n";
+    k += "        const gd_u32 lim = (P.n - base) < 256u ? (P.n - base) : 256u;\n";
+    k += "#pragma unroll 4\n";
+    k += "        for (gd_u32 t = 0; t < lim; ++t) {\n";
+    k += "            const float dx = tx[t] - sx, dy = ty[t] - sy;\n";
+    k += "            const float dist = gd_max(gd_length2(dx, dy), 0.001f);\n";
+    k += "            const float dirx = dx / dist, diry = dy / dist;\n";
+    k += "            const float f = " + law_expr(ir) + ";\n";
+    k += "            const bool self = (base + t) == idx;\n";
+    k += "            fx = self ? fx : fx + dirx * f;\n";
+    k += "            fy = self ? fy : fy + diry * f;\n";
+    k += "        }\n";
+    k += "        __syncthreads();\n";
+    k += "    }\n";
+    k += "    if (!live) return;\n";
+    k += "    float vx = P.vx[idx] * " + float_literal(ir.gravity.damping) + " + fx * P.dt;\n";
+    k += "    float vy = P.vy[idx] * " + float_literal(ir.gravity.damping) + " + fy * P.dt;\n";
+    k += "    float px = sx + vx * P.dt, py = sy + vy * P.dt;\n";
+    if (ir.gravity.bounds == Bounds::Reflect) {
+        k += "    if (px < -1.0f) { px = -1.0f; vx = -vx; }\n    if (px > 1.0f) { px = 1.0f; vx = -vx; }\n";
+        k += "    if (py < -1.0f) { py = -1.0f; vy = -vy; }\n    if (py > 1.0f) { py = 1.0f; vy = -vy; }\n";
+    } else if (ir.gravity.bounds == Bounds::Wrap) {
+        k += "    px = gd_fract((px + 1.0f) * 0.5f) * 2.0f - 1.0f;\n    py = gd_fract((py + 1.0f) * 0.5f) * 2.0f - 1.0f;\n";
+    }
+    k += "    P.xout[idx] = px; P.yout[idx] = py; P.vx[idx] = vx; P.vy[idx] = vy;\n";
+    k += "}\n";
+    return k;
+}
+
+}  // namespace game

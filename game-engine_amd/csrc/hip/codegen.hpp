@@ -1,0 +1,18 @@
+// Kernel generator interface (see codegen.cpp).
+#pragma once
+#include "../front/front.hpp"
+#include <string>
+
+namespace game {
+
+struct KernelShape {
+    uint32_t pixels_per_lane = 1;   // consecutive pixels in x handled by one lane
+    uint32_t time_slot = 0;         // index in the frame row of fract(u_time/120)*120
+    uint32_t aspect_slot = 0;       // index in the frame row of u_resolution.x / u_resolution.y
+};
+
+std::string float_literal(float v);
+std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape);
+std::string generate_gravity_kernel(const Ir& ir);
+
+}  // namespace game

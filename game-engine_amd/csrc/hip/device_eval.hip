@@ -1,0 +1,122 @@
+// Diagnostics compiled ahead of time for gfx950: element-wise evaluation of the device math and
+// noise functions on caller-supplied arrays (so tests can compare them bit-for-bit with a CPU
+// restatement), and exhaustive self-checks of the hardware instructions the device code leans on
+// (v_fract_f32, v_max_f32, v_min_f32) against their defining formulas over all 2^32 inputs.
+#include <hip/hip_runtime.h>
+#include "../front/capi_internal.hpp"
+#include "game_device.h"
+
+using namespace game;
+
+namespace {
+
+enum EvalOp { EV_FRACT = 0, EV_SIN, EV_COS, EV_ATAN2, EV_HASH2, EV_NOISE2, EV_SIMPLEX, EV_VORONOI, EV_EXP2, EV_LOG2, EV_POW,
+              EV_MAX, EV_MIN, EV_FBM6, EV_SQRT, EV_DIV, EV_SMOOTHSTEP_GLOW, EV_MOD, EV_COUNT };
+
+__global__ void eval_kernel(int op, uint32_t n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = a[i], y = b ? b[i] : 0.0f, r = 0.0f;
+    switch (op) {
+    case EV_FRACT: r = gd_fract(x); break;
+    case EV_SIN: r = gd_sin(x); break;
+    case EV_COS: r = gd_cos(x); break;
+    case EV_ATAN2: r = gd_atan2(x, y); break;
+    case EV_HASH2: r = gd_hash2(x, y); break;
+    case EV_NOISE2: r = gd_noise2(x, y); break;
+    case EV_SIMPLEX: r = gd_simplex2d(x, y); break;
+    case EV_VORONOI: r = gd_voronoi2d(x, y, 5.0f); break;
+    case EV_EXP2: r = gd_exp2(x); break;
+    case EV_LOG2: r = gd_log2(x); break;
+    case EV_POW: r = gd_pow(x, y); break;
+    case EV_MAX: r = gd_max(x, y); break;
+    case EV_MIN: r = gd_min(x, y); break;
+    case EV_FBM6: r = gd_fbm2(x, y, 6, 0.5f, 2.0f); break;
+    case EV_SQRT: r = gd_sqrt(x); break;
+    case EV_DIV: r = x / y; break;
+    case EV_SMOOTHSTEP_GLOW: r = gd_smoothstep(0.005f, -0.005f, x); break;
+    case EV_MOD: r = gd_mod(x, y); break;
+    default: break;
+    }
+    out[i] = r;
+}
+
+// which: 0 = fract(x) for every bit pattern x; 1 = max(x, c), 2 = min(x, c) for every x and the
+// probe constants below.
+__global__ void exhaustive_kernel(int which, unsigned long long* mismatches, uint32_t* first_bad)
+{
+    const float probes[6] = {0.0f, -0.0f, 1.0f, -1.0f, __builtin_inff(), __builtin_nanf("")};
+    unsigned long long total = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (unsigned long long v = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; v < (1ull << 32); v += total) {
+        float x = gd_from_bits((gd_u32)v);
+        if (which == 0) {
+            float hw = gd_fract(x);
+            float f = x - gd_floor(x);
+            float want = (f != f) ? f : (f < 1.0f ? f : 0x1.fffffep-1f);
+            bool same = (hw != hw && want != want) || gd_bits(hw) == gd_bits(want);
+            if (!same) { ++bad; atomicMin(first_bad, (gd_u32)v); }
+        } else {
+            for (int p = 0; p < 6; ++p) {
+                float c = probes[p];
+                float hw = which == 1 ? gd_max(x, c) : gd_min(x, c);
+                float want;
+                if (x != x) want = c;
+                else if (c != c) want = x;
+                else if (x == c) {
+                    bool xneg = gd_bits(x) >> 31;
+                    want = which == 1 ? (xneg ? c : x) : (xneg ? x : c);
+                } else want = which == 1 ? (x > c ? x : c) : (x < c ? x : c);
+                bool same = (hw != hw && want != want) || gd_bits(hw) == gd_bits(want);
+                if (!same) { ++bad; atomicMin(first_bad, (gd_u32)v); }
+            }
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+int hip_err(const char* what, hipError_t e) { return set_error(GAME_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
+#define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return hip_err(#expr, _e); } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out)
+{
+    if (op < 0 || op >= EV_COUNT || !a || !out || n == 0) return set_error(GAME_E_ARGUMENT, "game_hip_eval: bad argument");
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    size_t bytes = (size_t)n * 4;
+    HIP_TRY(hipMalloc((void**)&da, bytes));
+    HIP_TRY(hipMalloc((void**)&dout, bytes));
+    HIP_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+    if (b) { HIP_TRY(hipMalloc((void**)&db, bytes)); HIP_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(eval_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op, n, da, db, dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(dout);
+    if (db) (void)hipFree(db);
+    return GAME_OK;
+}
+
+int game_hip_check_exhaustive(int which, uint64_t* mismatches, uint32_t* first_bad)
+{
+    if (which < 0 || which > 2 || !mismatches || !first_bad) return set_error(GAME_E_ARGUMENT, "game_hip_check_exhaustive: bad argument");
+    unsigned long long* dm = nullptr;
+    uint32_t* df = nullptr;
+    HIP_TRY(hipMalloc((void**)&dm, 8));
+    HIP_TRY(hipMalloc((void**)&df, 4));
+    HIP_TRY(hipMemset(dm, 0, 8));
+    HIP_TRY(hipMemset(df, 0xff, 4));
+    hipLaunchKernelGGL(exhaustive_kernel, dim3(4096), dim3(256), 0, 0, which, dm, df);
+    HIP_TRY(hipGetLastError());
+    unsigned long long m = 0;
+    HIP_TRY(hipMemcpy(&m, dm, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(first_bad, df, 4, hipMemcpyDeviceToHost));
+    *mismatches = m;
+    (void)hipFree(dm); (void)hipFree(df);
+    return GAME_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,486 @@
+// game_device.h — hand-written gfx950 device functions for the fused per-pixel kernel.
+//
+// One __device__ function per GAME builtin; the kernel generator strings calls to them together
+// in pipeline order with the stage arguments baked in as literals, so a whole layer lives in
+// VGPRs from `p` to the packed RGBA8 store. Semantics follow the GLSL ES 3.00 text the reference
+// compiler emits (game-compiler/src/codegen/glsl.rs; line numbers are cited per function), one
+// FP32 rounding per GLSL operator: this file must be compiled with -ffp-contract=off, and fused
+// multiply-adds appear only where written as __builtin_fmaf (inside the sin/cos/atan kernels).
+//
+// The file is compiled by hiprtc (no system headers) and, for the unit-test kernels, by hipcc.
+#pragma once
+
+#define GD static __device__ __forceinline__
+
+typedef unsigned int gd_u32;
+
+// ── scalar helpers ──────────────────────────────────────────────────────────────────────
+GD gd_u32 gd_bits(float f) { return __builtin_bit_cast(gd_u32, f); }
+GD float gd_from_bits(gd_u32 u) { return __builtin_bit_cast(float, u); }
+GD float gd_abs(float x) { return __builtin_fabsf(x); }
+GD float gd_floor(float x) { return __builtin_floorf(x); }           // v_floor_f32
+GD float gd_max(float a, float b) { return __builtin_fmaxf(a, b); }  // v_max_f32: NaN -> other operand, -0 < +0
+GD float gd_min(float a, float b) { return __builtin_fminf(a, b); }  // v_min_f32
+GD float gd_clamp(float x, float lo, float hi) { return gd_min(gd_max(x, lo), hi); }
+GD float gd_sqrt(float x) { return __builtin_sqrtf(x); }             // correctly rounded (hipcc/hiprtc default)
+// v_fract_f32: x - floor(x) clamped to the largest float below 1; NaN for NaN and infinities.
+GD float gd_fract(float x) { return __builtin_amdgcn_fractf(x); }
+GD float gd_mod(float x, float y) { return x - y * gd_floor(x / y); }
+GD float gd_step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
+GD float gd_mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+GD float gd_smoothstep(float e0, float e1, float x)
+{
+    float t = gd_clamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+GD float gd_length2(float x, float y) { return gd_sqrt(x * x + y * y); }
+
+// ── sin / cos / atan ────────────────────────────────────────────────────────────────────
+// GLSL does not fix the precision of these; the render path uses a fixed algorithm made of
+// correctly rounded operations only, so every IEEE machine gets the same bits:
+// k = rint(x * 2/pi), three-constant Cody-Waite reduction with fma for |x| <= 32768, double
+// precision two-constant reduction up to 2^31, argument treated as 0 beyond; Cephes
+// single-precision minimax polynomials on [-pi/4, pi/4]; quadrant from k mod 4.
+GD void gd_sincos(float x, float& s_out, float& c_out)
+{
+    float ax = gd_abs(x);
+    float r;
+    int q;
+    if (!(ax < __builtin_inff())) { s_out = c_out = x - x; return; }
+    if (ax <= 32768.0f) {
+        float k = __builtin_rintf(x * 0.636619772f);
+        r = __builtin_fmaf(k, -1.5703125f, x);
+        r = __builtin_fmaf(k, -4.837512969970703125e-4f, r);
+        r = __builtin_fmaf(k, -7.54978995489188216e-8f, r);
+        q = (int)k & 3;
+    } else if (ax >= 2147483648.0f) {
+        r = 0.0f;
+        q = 0;
+    } else {
+        double xd = (double)x;
+        double kd = __builtin_rint(xd * 0.63661977236758134308);
+        double rd = __builtin_fma(-kd, 1.57079632673412561417e+00, xd);
+        rd = __builtin_fma(-kd, 6.07710050650619224932e-11, rd);
+        r = (float)rd;
+        q = (int)(kd - 4.0 * __builtin_floor(kd * 0.25));
+    }
+    float z = r * r;
+    float ps = __builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    float s = __builtin_fmaf(ps * z, r, r);
+    float pc = __builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    float c = __builtin_fmaf(pc * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+    float ss = (q & 1) ? c : s;
+    float cc = (q & 1) ? s : c;
+    s_out = (q & 2) ? -ss : ss;
+    c_out = ((q + 1) & 2) ? -cc : cc;
+}
+GD float gd_sin(float x) { float s, c; gd_sincos(x, s, c); return s; }
+GD float gd_cos(float x) { float s, c; gd_sincos(x, s, c); return c; }
+GD float gd_tan(float x) { float s, c; gd_sincos(x, s, c); return s / c; }
+
+GD float gd_atan2(float y, float x)
+{
+    if (x != x || y != y) return x + y;
+    float ax = gd_abs(x), ay = gd_abs(y);
+    float mx = ax > ay ? ax : ay;
+    float mn = ax > ay ? ay : ax;
+    float t;
+    if (mx == 0.0f) t = 0.0f;
+    else if (mn == __builtin_inff()) t = 1.0f;
+    else t = mn / mx;
+    float base = 0.0f;
+    if (t > 0.4142135623730950f) { base = 0.78539816339744830962f; t = (t - 1.0f) / (t + 1.0f); }
+    float z = t * t;
+    float p = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z,
+                             -3.33329491539e-1f);
+    float a = base + __builtin_fmaf(p * z, t, t);
+    if (ay > ax) a = 1.57079632679489661923f - a;
+    if (gd_bits(x) >> 31) a = 3.14159265358979323846f - a;
+    if (gd_bits(y) >> 31) a = -a;
+    return a;
+}
+
+// exp2 / log2 / pow: used by gravity force laws only.
+GD float gd_exp2(float x)
+{
+    if (x != x) return x;
+    if (x > 128.0f) return __builtin_inff();
+    if (x < -150.0f) return 0.0f;
+    float k = __builtin_rintf(x);
+    float f = x - k;
+    float p = 1.530178e-4f;
+    p = __builtin_fmaf(p, f, 1.339887e-3f);
+    p = __builtin_fmaf(p, f, 9.618437e-3f);
+    p = __builtin_fmaf(p, f, 5.550357e-2f);
+    p = __builtin_fmaf(p, f, 2.402265e-1f);
+    p = __builtin_fmaf(p, f, 6.931472e-1f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    int ki = (int)k;
+    int k1 = ki / 2, k2 = ki - k1;
+    float s1 = gd_from_bits((gd_u32)(k1 + 127) << 23);
+    float s2 = gd_from_bits((gd_u32)(k2 + 127) << 23);
+    return p * s1 * s2;
+}
+GD float gd_log2(float x)
+{
+    if (x != x || x < 0.0f) return x - x + (x - x) / (x - x);
+    if (x == 0.0f) return -__builtin_inff();
+    if (x == __builtin_inff()) return x;
+    int e = 0;
+    gd_u32 u = gd_bits(x);
+    if (u < 0x00800000u) { x = x * 8388608.0f; u = gd_bits(x); e = -23; }
+    int k = (int)((u + 0x004afb0du) >> 23) - 127;
+    e += k;
+    float m = gd_from_bits((gd_u32)((int)u - k * 0x00800000));
+    float f = m - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float p = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0.2222222222f, z, 0.2857142857f), z, 0.4f), z, 0.6666666667f), z, 2.0f);
+    float ln_m = s * p;
+    return __builtin_fmaf(ln_m, 1.44269504088896340736f, (float)e);
+}
+GD float gd_pow(float x, float y) { return gd_exp2(y * gd_log2(x)); }
+GD float gd_exp(float x) { return gd_exp2(x * 1.44269504088896340736f); }
+GD float gd_log(float x) { return gd_log2(x) * 0.69314718055994530942f; }
+
+// ── noise (glsl.rs:132-220) ─────────────────────────────────────────────────────────────
+// hash2 (glsl.rs:134-138). The three fract/multiply lanes of the GLSL vec3 collapse to two
+// because p3.x == p3.z; the sum is evaluated left to right exactly as dot() is written.
+GD float gd_hash2(float px, float py)
+{
+    float x = gd_fract(px * 0.1031f);
+    float y = gd_fract(py * 0.1031f);
+    float z = x;
+    float d = x * (y + 33.33f) + y * (z + 33.33f) + z * (x + 33.33f);
+    x = x + d; y = y + d; z = z + d;
+    return gd_fract((x + y) * z);
+}
+
+// noise2 (glsl.rs:141-150): value noise, bilinear mix of four lattice hashes, remapped to [-1, 1].
+GD float gd_noise2(float px, float py)
+{
+    float ix = gd_floor(px), iy = gd_floor(py);
+    float fx = gd_fract(px), fy = gd_fract(py);
+    float ux = fx * fx * (3.0f - 2.0f * fx);
+    float uy = fy * fy * (3.0f - 2.0f * fy);
+    float a = gd_hash2(ix, iy);
+    float b = gd_hash2(ix + 1.0f, iy);
+    float c = gd_hash2(ix, iy + 1.0f);
+    float d = gd_hash2(ix + 1.0f, iy + 1.0f);
+    return gd_mix(gd_mix(a, b, ux), gd_mix(c, d, ux), uy) * 2.0f - 1.0f;
+}
+
+GD int gd_octaves(float o)   // int(x), clamped to [0, 32]
+{
+    if (!(o >= 1.0f)) return 0;
+    if (o >= 32.0f) return 32;
+    return (int)o;
+}
+
+// fbm2 (glsl.rs:155-169). With a literal octave count the loop unrolls and the amplitude /
+// frequency / max_val recurrences fold to constants.
+GD float gd_fbm2(float px, float py, int octaves, float persistence, float lacunarity)
+{
+    float value = 0.0f, amplitude = 1.0f, frequency = 1.0f, max_val = 0.0f;
+    float qx = px, qy = py;
+#pragma unroll
+    for (int i = 0; i < octaves; i++) {
+        value = value + gd_noise2(qx * frequency, qy * frequency) * amplitude;
+        max_val = max_val + amplitude;
+        amplitude = amplitude * persistence;
+        frequency = frequency * lacunarity;
+        float nx = qx * 0.8f - qy * 0.6f;
+        float ny = qx * 0.6f + qy * 0.8f;
+        qx = nx; qy = ny;
+    }
+    return value / max_val;
+}
+
+GD float gd_permute(float x) { return gd_mod((x * 34.0f + 1.0f) * x, 289.0f); }   // glsl.rs:173-175
+
+GD float gd_simplex2d(float vx, float vy)   // glsl.rs:176-198
+{
+    const float Cx = 0.211324865405187f, Cy = 0.366025403784439f, Cz = -0.577350269189626f, Cw = 0.024390243902439f;
+    float dv = vx * Cy + vy * Cy;
+    float ix = gd_floor(vx + dv), iy = gd_floor(vy + dv);
+    float di = ix * Cx + iy * Cx;
+    float x0x = vx - ix + di, x0y = vy - iy + di;
+    bool gt = x0x > x0y;
+    float i1x = gt ? 1.0f : 0.0f, i1y = gt ? 0.0f : 1.0f;
+    float x12x = x0x + Cx, x12y = x0y + Cx, x12z = x0x + Cz, x12w = x0y + Cz;
+    x12x = x12x - i1x; x12y = x12y - i1y;
+    ix = gd_mod(ix, 289.0f); iy = gd_mod(iy, 289.0f);
+    float p0 = gd_permute(gd_permute(iy + 0.0f) + ix + 0.0f);
+    float p1 = gd_permute(gd_permute(iy + i1y) + ix + i1x);
+    float p2 = gd_permute(gd_permute(iy + 1.0f) + ix + 1.0f);
+    float m0 = gd_max(0.5f - (x0x * x0x + x0y * x0y), 0.0f);
+    float m1 = gd_max(0.5f - (x12x * x12x + x12y * x12y), 0.0f);
+    float m2 = gd_max(0.5f - (x12z * x12z + x12w * x12w), 0.0f);
+    m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
+    m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
+    float xv0 = 2.0f * gd_fract(p0 * Cw) - 1.0f;
+    float xv1 = 2.0f * gd_fract(p1 * Cw) - 1.0f;
+    float xv2 = 2.0f * gd_fract(p2 * Cw) - 1.0f;
+    float h0 = gd_abs(xv0) - 0.5f, h1 = gd_abs(xv1) - 0.5f, h2 = gd_abs(xv2) - 0.5f;
+    float a00 = xv0 - gd_floor(xv0 + 0.5f), a01 = xv1 - gd_floor(xv1 + 0.5f), a02 = xv2 - gd_floor(xv2 + 0.5f);
+    m0 = m0 * (1.79284291400159f - 0.85373472095314f * (a00 * a00 + h0 * h0));
+    m1 = m1 * (1.79284291400159f - 0.85373472095314f * (a01 * a01 + h1 * h1));
+    m2 = m2 * (1.79284291400159f - 0.85373472095314f * (a02 * a02 + h2 * h2));
+    float g0 = a00 * x0x + h0 * x0y;
+    float g1 = a01 * x12x + h1 * x12y;
+    float g2 = a02 * x12z + h2 * x12w;
+    return 130.0f * (m0 * g0 + m1 * g1 + m2 * g2);
+}
+
+GD float gd_voronoi2d(float px, float py, float scale)   // glsl.rs:202-219
+{
+    float psx = px * scale, psy = py * scale;
+    float ipx = gd_floor(psx), ipy = gd_floor(psy);
+    float fpx = gd_fract(psx), fpy = gd_fract(psy);
+    float d = 1.0f;
+#pragma unroll
+    for (int y = -1; y <= 1; y++) {
+#pragma unroll
+        for (int x = -1; x <= 1; x++) {
+            float nx = (float)x, ny = (float)y;
+            float cx = ipx + nx, cy = ipy + ny;
+            float hx = gd_fract(gd_sin(cx * 127.1f + cy * 311.7f) * 43758.5453f);
+            float hy = gd_fract(gd_sin(cx * 269.5f + cy * 183.3f) * 43758.5453f);
+            float ptx = nx + hx - fpx, pty = ny + hy - fpy;
+            d = gd_min(d, ptx * ptx + pty * pty);
+        }
+    }
+    return gd_sqrt(d);
+}
+
+GD float gd_apply_glow(float d, float intensity)   // glsl.rs:102-107
+{
+    float core = gd_smoothstep(0.005f, -0.005f, d);
+    float halo = intensity / (1.0f + gd_max(d, 0.0f) * gd_max(d, 0.0f) * intensity * intensity * 16.0f);
+    return core + halo;
+}
+
+// ── pipeline state ──────────────────────────────────────────────────────────────────────
+// Per-pixel registers of one layer: position p, the signed distance, the colour, plus the
+// frame-constant values every stage may read.
+struct GdPix {
+    float px, py;          // `p`
+    float sdf;             // `sdf_result`
+    float r, g, b, a;      // `color_result`
+    float uvx, uvy;        // `uv`
+    float time;            // fract(u_time / 120) * 120
+    float bass, mid, treble;
+};
+
+// SDF generators: Position -> Sdf
+GD void gb_circle(GdPix& s, float radius) { s.sdf = gd_length2(s.px, s.py) - radius; }                 // glsl.rs:265-268
+GD void gb_ring(GdPix& s, float radius, float width) { s.sdf = gd_abs(gd_length2(s.px, s.py) - radius) - width; }  // :269-273
+GD void gb_star(GdPix& s, float points, float radius, float inner)                                      // :274-288
+{
+    float an = 3.14159265359f / points;
+    float a = gd_atan2(s.py, s.px);
+    float sector = gd_mod(a + an, 2.0f * an) - an;
+    float len = gd_length2(s.px, s.py);
+    float sc, ss;
+    gd_sincos(sector, ss, sc);
+    float spx = sc * len, spy = gd_abs(ss) * len;
+    float ans, anc;
+    gd_sincos(an, ans, anc);
+    float apx = radius, apy = 0.0f;
+    float bpx = inner * anc, bpy = inner * ans;
+    float bax = bpx - apx, bay = bpy - apy;
+    float t = gd_clamp(((spx - apx) * bax + (spy - apy) * bay) / (bax * bax + bay * bay), 0.0f, 1.0f);
+    s.sdf = gd_length2(spx - apx - bax * t, spy - apy - bay * t);
+}
+GD void gb_box(GdPix& s, float w, float h)                                                              // :289-294
+{
+    float dx = gd_abs(s.px) - w, dy = gd_abs(s.py) - h;
+    s.sdf = gd_length2(gd_max(dx, 0.0f), gd_max(dy, 0.0f)) + gd_min(gd_max(dx, dy), 0.0f);
+}
+GD void gb_polygon(GdPix& s, float sides, float radius)                                                 // :295-304
+{
+    float a = gd_atan2(s.py, s.px);
+    float r = gd_length2(s.px, s.py);
+    float an = 6.28318530718f / sides;
+    float sector = gd_cos(gd_floor(0.5f + a / an) * an - a) * r;
+    s.sdf = sector - radius;
+}
+GD void gb_simplex(GdPix& s, float scale) { s.sdf = gd_simplex2d(s.px * scale, s.py * scale); }         // :305-308
+GD void gb_voronoi(GdPix& s, float scale) { s.sdf = gd_voronoi2d(s.px, s.py, scale); }                  // :309-312
+GD void gb_concentric_waves(GdPix& s, float amplitude, float width, float frequency)                    // :313-319
+{
+    float dist = gd_length2(s.px, s.py);
+    s.sdf = amplitude * gd_sin(dist * frequency * 6.28318530718f - s.time * width);
+}
+GD void gb_fbm(GdPix& s, float scale, int octaves, float persistence, float lacunarity)                 // :320-326
+{
+    s.sdf = gd_fbm2(s.px * scale, s.py * scale, octaves, persistence, lacunarity);
+}
+
+// Transforms: Position -> Position
+GD void gb_rotate(GdPix& s, float angle)                                                                // :329-334
+{
+    float rs, rc;
+    gd_sincos(angle, rs, rc);
+    float nx = s.px * rc - s.py * rs, ny = s.px * rs + s.py * rc;
+    s.px = nx; s.py = ny;
+}
+GD void gb_translate(GdPix& s, float x, float y) { s.px = s.px - x; s.py = s.py - y; }                  // :335-339
+GD void gb_scale(GdPix& s, float k) { s.px = s.px / k; s.py = s.py / k; }                               // :340-343
+GD void gb_twist(GdPix& s, float amount)                                                                // :344-349
+{
+    float ts, tc;
+    gd_sincos(s.py * amount, ts, tc);
+    float nx = s.px * tc - s.py * ts, ny = s.px * ts + s.py * tc;
+    s.px = nx; s.py = ny;
+}
+GD void gb_mirror(GdPix& s, float axis)                                                                 // :350-354
+{
+    if (axis < 0.5f) s.px = gd_abs(s.px); else s.py = gd_abs(s.py);
+}
+GD void gb_repeat(GdPix& s, float count)                                                                // :355-361
+{
+    float ra = 6.28318530718f / count;
+    float a = gd_atan2(s.py, s.px);
+    a = gd_mod(a + ra * 0.5f, ra) - ra * 0.5f;
+    float len = gd_length2(s.px, s.py);
+    float as, ac;
+    gd_sincos(a, as, ac);
+    s.px = ac * len; s.py = as * len;
+}
+GD void gb_domain_warp(GdPix& s, float amount, float freq)                                              // :362-366
+{
+    float n0 = gd_noise2(s.px * freq, s.py * freq);
+    float n1 = gd_noise2(s.px * freq + 5.2f, s.py * freq + 1.3f);
+    s.px = s.px + n0 * amount; s.py = s.py + n1 * amount;
+}
+GD void gb_curl_noise(GdPix& s, float frequency, float amplitude)                                       // :367-377
+{
+    const float eps = 0.001f;
+    float bx = s.px * frequency, by = s.py * frequency;
+    float n0 = gd_noise2(bx + 0.0f, by + eps);
+    float n1 = gd_noise2(bx - 0.0f, by - eps);
+    float n2 = gd_noise2(bx + eps, by + 0.0f);
+    float n3 = gd_noise2(bx - eps, by - 0.0f);
+    float cx = (n0 - n1) / (2.0f * eps);
+    float cy = -(n2 - n3) / (2.0f * eps);
+    float len = gd_length2(cx, cy);
+    s.px = s.px + cx / len * amplitude; s.py = s.py + cy / len * amplitude;
+}
+GD void gb_displace(GdPix& s, float strength)                                                           // :378-381
+{
+    float t5 = s.time * 0.5f;
+    float n0 = gd_noise2(s.px * 3.0f + t5, s.py * 3.0f + t5);
+    float n1 = gd_noise2(s.px * 3.0f + 5.2f + t5, s.py * 3.0f + 1.3f + t5);
+    s.px = s.px + n0 * strength; s.py = s.py + n1 * strength;
+}
+
+// SDF modifiers: Sdf -> Sdf
+GD void gb_mask_arc(GdPix& s, float angle)                                                              // :384-389
+{
+    float theta = gd_atan2(s.px, s.py) + 3.14159265359f;
+    s.sdf = (theta < angle) ? s.sdf : 999.0f;
+}
+GD void gb_threshold(GdPix& s, float cutoff) { s.sdf = (s.sdf < cutoff) ? -1.0f : 1.0f; }               // :390-393
+GD void gb_onion(GdPix& s, float thickness) { s.sdf = gd_abs(s.sdf) - thickness; }                      // :394-397
+GD void gb_round(GdPix& s, float radius) { s.sdf = s.sdf - radius; }                                    // :398-401
+
+// Bridges: Sdf -> Color
+GD void gb_glow(GdPix& s, float intensity) { float g = gd_apply_glow(s.sdf, intensity); s.r = s.g = s.b = g; s.a = 1.0f; }  // :404-408
+GD void gb_shade(GdPix& s, float r, float g, float b)                                                   // :409-416
+{
+    float m = gd_smoothstep(0.005f, -0.005f, s.sdf);
+    s.r = r * m; s.g = g * m; s.b = b * m; s.a = 1.0f;
+}
+GD void gb_emissive(GdPix& s, float intensity) { float g = gd_apply_glow(s.sdf, intensity); s.r = s.g = s.b = g; s.a = g; }  // :417-421
+GD void gb_palette(GdPix& s, float ar, float ag, float ab, float br, float bg, float bb, float cr, float cg, float cb,
+                   float dr, float dg, float db)                                                        // :422-437, :222-226
+{
+    float t = gd_clamp(s.sdf * 0.5f + 0.5f, 0.0f, 1.0f);
+    s.r = ar + br * gd_cos(6.28318f * (cr * t + dr));
+    s.g = ag + bg * gd_cos(6.28318f * (cg * t + dg));
+    s.b = ab + bb * gd_cos(6.28318f * (cb * t + db));
+    s.a = 1.0f;
+}
+
+// Colour processors: Color -> Color
+GD void gb_tint(GdPix& s, float r, float g, float b) { s.r = s.r * r; s.g = s.g * g; s.b = s.b * b; s.a = 1.0f; }   // :440-445
+GD void gb_bloom(GdPix& s, float threshold, float strength)                                             // :446-452
+{
+    float lum = s.r * 0.299f + s.g * 0.587f + s.b * 0.114f;
+    float add = gd_max(lum - threshold, 0.0f) * strength;
+    s.r = s.r + add; s.g = s.g + add; s.b = s.b + add; s.a = 1.0f;
+}
+GD void gb_grain(GdPix& s, float amount)                                                                // :453-457
+{
+    float n = gd_fract(gd_sin(s.px * 12.9898f + s.py * 78.233f + s.time) * 43758.5453f);
+    float add = (n - 0.5f) * amount;
+    s.r = s.r + add; s.g = s.g + add; s.b = s.b + add;
+}
+GD void gb_vignette(GdPix& s, float strength, float radius)                                             // :458-464
+{
+    float dist = gd_length2(s.uvx, s.uvy);
+    float f = 1.0f - gd_smoothstep(radius, radius + strength, dist);
+    s.r = s.r * f; s.g = s.g * f; s.b = s.b * f;
+}
+GD void gb_chromatic(GdPix& s, float offset)                                                            // :465-472
+{
+    float len = gd_length2(s.uvx, s.uvy);
+    float dirx = s.uvx / len * offset;
+    s.r = s.r * (1.0f + dirx);
+    s.b = s.b * (1.0f - dirx);
+}
+GD void gb_tonemap(GdPix& s, float exposure)                                                            // :473-478
+{
+    float r = s.r * exposure, g = s.g * exposure, b = s.b * exposure;
+    s.r = r / (r + 1.0f); s.g = g / (g + 1.0f); s.b = b / (b + 1.0f);
+}
+GD void gb_scanlines(GdPix& s, float frequency, float intensity)                                        // :479-484
+{
+    float v = gd_sin(s.uvy * frequency * 3.14159265359f) * intensity;
+    float f = 1.0f - v * 0.5f;
+    s.r = s.r * f; s.g = s.g * f; s.b = s.b * f;
+}
+GD void gb_saturate_color(GdPix& s, float amount)                                                       // :485-489
+{
+    float lum = s.r * 0.299f + s.g * 0.587f + s.b * 0.114f;
+    s.r = gd_mix(lum, s.r, amount); s.g = gd_mix(lum, s.g, amount); s.b = gd_mix(lum, s.b, amount);
+}
+GD void gb_glitch(GdPix& s, float intensity)                                                            // :490-501
+{
+    float gt = gd_floor(s.time * 10.0f);
+    float n = gd_fract(gd_sin(gt * 43758.5453f + s.py * 100.0f) * 43758.5453f);
+    float shift = (n - 0.5f) * intensity * 0.1f;
+    float block = gd_step(1.0f - intensity * 0.3f, gd_fract(gd_sin(gt * 12.9898f + gd_floor(s.py * 20.0f)) * 43758.5453f));
+    s.r = s.r + shift * block;
+    s.b = s.b - shift * block;
+}
+GD void gb_blend(GdPix& s, float factor) { s.r = s.r * factor; s.g = s.g * factor; s.b = s.b * factor; }   // :502-505
+
+// Full-screen generators: Position -> Color
+GD void gb_gradient(GdPix& s) { float t = s.uvy * 0.5f + 0.5f; s.r = s.g = s.b = t; s.a = 1.0f; }       // :508-515
+GD void gb_spectrum(GdPix& s, float bass, float mid, float treble)                                      // :516-525
+{
+    float sx = s.uvx * 0.5f + 0.5f;
+    s.r = gd_smoothstep(0.0f, 0.33f, sx) * (s.bass + bass);
+    s.g = gd_smoothstep(0.33f, 0.66f, sx) * (s.mid + mid);
+    s.b = gd_smoothstep(0.66f, 1.0f, sx) * (s.treble + treble);
+    s.a = 1.0f;
+}
+
+// Memory feedback (game-compiler/src/codegen/memory.rs:38-45): mix with the previous frame's
+// RGBA8 texel at the same pixel.
+GD void gb_memory_mix(GdPix& s, gd_u32 prev, float decay)
+{
+    float pr = (float)(prev & 0xffu) / 255.0f, pg = (float)((prev >> 8) & 0xffu) / 255.0f;
+    float pb = (float)((prev >> 16) & 0xffu) / 255.0f, pa = (float)(prev >> 24) / 255.0f;
+    s.r = gd_mix(s.r, pr, decay); s.g = gd_mix(s.g, pg, decay);
+    s.b = gd_mix(s.b, pb, decay); s.a = gd_mix(s.a, pa, decay);
+}
+
+// Framebuffer write: RGBA8 unorm, round(clamp(c, 0, 1) * 255), R in the low byte.
+GD gd_u32 gd_unorm8(float c) { return (gd_u32)(gd_min(gd_max(c, 0.0f), 1.0f) * 255.0f + 0.5f); }
+GD gd_u32 gd_pack_rgba8(float r, float g, float b, float a)
+{
+    return gd_unorm8(r) | (gd_unorm8(g) << 8) | (gd_unorm8(b) << 16) | (gd_unorm8(a) << 24);
+}

@@ -1,0 +1,510 @@
+// GPU runtime behind include/game_hip.h: hiprtc assembly of the per-cinematic kernels, the frame
+// scheduler (frame-batched launches into a ring of RGBA8 frames resident in HBM), the memory
+// feedback store (previous frame = previous ring slot) and the SoA particle integrator.
+// Stands in for the reference's browser-side renderer loop (game-compiler/src/runtime/helpers.rs:
+// 148-235), its intended ping-pong memory runtime (game-compiler/src/codegen/memory.rs:102-147)
+// and GameGravitySim (game-compiler/src/codegen/gravity.rs:123-191).
+#include "../front/capi_internal.hpp"
+#include "codegen.hpp"
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+using namespace game;
+
+static const char* const kDeviceHeader =
+#include "game_device_src.inc"
+    ;
+
+struct game_hip_ctx {
+    Ir ir;
+    int device = 0;
+    uint32_t w = 0, h = 0;
+    hipStream_t stream = nullptr;
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    std::string source;
+    KernelShape shape;
+    uint32_t row_floats = 0, ustride = 0;
+    // frame ring
+    uint32_t ring = 0, next_slot = 0;
+    int last_slot = -1;
+    uint32_t* frames = nullptr;
+    float* utab_dev = nullptr;
+    size_t utab_cap = 0;
+    std::vector<float> utab_host;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.0f;
+    uint32_t last_launches = 0;
+    // particles
+    hipModule_t gmod = nullptr;
+    hipFunction_t gfn = nullptr;
+    std::string gsource;
+    uint32_t n = 0;
+    float* px[2] = {nullptr, nullptr};
+    float* py[2] = {nullptr, nullptr};
+    float* vx = nullptr;
+    float* vy = nullptr;
+    int cur = 0;
+    float sim_time = 0.0f;
+};
+
+namespace {
+
+struct FrameParams {
+    uint32_t* out;
+    const uint32_t* prev;
+    const float* utab;
+    unsigned long long frame_pixels;
+    uint32_t w, h, row0, rows;
+    uint32_t ustride, slot0, ring, frame0;
+    float inv_w, inv_h;
+};
+struct GravityParams {
+    const float* xin; const float* yin;
+    float* xout; float* yout; float* vx; float* vy;
+    uint32_t n, first, count, pad;
+    float dt, time;
+};
+
+int hip_fail(const char* what, hipError_t e)
+{
+    return set_error(e == hipErrorNoDevice || e == hipErrorInvalidDevice ? GAME_E_NO_DEVICE : GAME_E_HIP,
+                     std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) return hip_fail(#expr, _e); \
+    } while (0)
+
+// Compiles HIP source for gfx950 with the device header attached. No device is needed.
+int compile_hip(const std::string& src, const char* name, std::vector<char>& code)
+{
+    hiprtcProgram prog;
+    const char* hdr_src[] = {kDeviceHeader};
+    const char* hdr_name[] = {"game_device.h"};
+    hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), name, 1, hdr_src, hdr_name);
+    if (r != HIPRTC_SUCCESS) return set_error(GAME_E_HIP, std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r));
+    // One rounding per source operator: contraction off; fma only where the source says fma.
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+    r = hiprtcCompileProgram(prog, 4, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return set_error(GAME_E_HIP, std::string("hiprtc compile of ") + name + " failed: " + hiprtcGetErrorString(r) + "\n" + log);
+    }
+    size_t n = 0;
+    hiprtcGetCodeSize(prog, &n);
+    code.resize(n);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    return GAME_OK;
+}
+
+KernelShape shape_for(const Ir& ir)
+{
+    KernelShape s;
+    s.pixels_per_lane = 1;
+    uint32_t row = BU_COUNT + (uint32_t)ir.uniforms.size();
+    s.time_slot = row;
+    s.aspect_slot = row + 1;
+    return s;
+}
+
+// fract as the kernels define it: x - floor(x), kept below 1.
+float host_fract(float x)
+{
+    float f = x - floorf(x);
+    if (f != f) return f;
+    return f < 1.0f ? f : 0x1.fffffep-1f;
+}
+
+int ensure_ring(game_hip_ctx* c, uint32_t ring)
+{
+    if (c->frames && c->ring == ring) return GAME_OK;
+    if (c->frames) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->frames)); c->frames = nullptr; }
+    size_t bytes = (size_t)ring * c->w * c->h * 4;
+    HIP_TRY(hipMalloc((void**)&c->frames, bytes));
+    HIP_TRY(hipMemsetAsync(c->frames, 0, bytes, c->stream));
+    c->ring = ring;
+    c->next_slot = 0;
+    c->last_slot = -1;
+    return GAME_OK;
+}
+
+int upload_rows(game_hip_ctx* c, const float* uniforms, uint32_t nframes)
+{
+    size_t need = (size_t)nframes * c->ustride;
+    c->utab_host.resize(need);
+    for (uint32_t f = 0; f < nframes; ++f) {
+        const float* src = uniforms + (size_t)f * c->row_floats;
+        float* dst = c->utab_host.data() + (size_t)f * c->ustride;
+        memcpy(dst, src, (size_t)c->row_floats * 4);
+        dst[c->shape.time_slot] = host_fract(src[BU_TIME] / 120.0f) * 120.0f;   // glsl.rs:56
+        dst[c->shape.aspect_slot] = src[BU_RES_X] / src[BU_RES_Y];              // glsl.rs:55
+    }
+    if (need > c->utab_cap) {
+        if (c->utab_dev) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->utab_dev)); c->utab_dev = nullptr; }
+        size_t cap = need < 4096 ? 4096 : need;
+        HIP_TRY(hipMalloc((void**)&c->utab_dev, cap * 4));
+        c->utab_cap = cap;
+    }
+    HIP_TRY(hipMemcpyAsync(c->utab_dev, c->utab_host.data(), need * 4, hipMemcpyHostToDevice, c->stream));
+    return GAME_OK;
+}
+
+int launch_frames(game_hip_ctx* c, uint32_t frame0, uint32_t count, uint32_t slot0, const uint32_t* prev, uint32_t row0,
+                  uint32_t rows)
+{
+    FrameParams P;
+    P.out = c->frames;
+    P.prev = prev;
+    P.utab = c->utab_dev;
+    P.frame_pixels = (unsigned long long)c->w * c->h;
+    P.w = c->w; P.h = c->h; P.row0 = row0; P.rows = rows;
+    P.ustride = c->ustride; P.slot0 = slot0; P.ring = c->ring; P.frame0 = frame0;
+    P.inv_w = 1.0f / (float)c->w;
+    P.inv_h = 1.0f / (float)c->h;
+    void* args[] = {&P};
+    uint32_t gx = (c->w + 32u * c->shape.pixels_per_lane - 1u) / (32u * c->shape.pixels_per_lane);
+    uint32_t gy = (rows + 7u) / 8u;
+    HIP_TRY(hipModuleLaunchKernel(c->fn, gx, gy, count, 256, 1, 1, 0, c->stream, args, nullptr));
+    return GAME_OK;
+}
+
+int render_impl(game_hip_ctx* c, const float* uniforms, uint32_t nframes, uint32_t row0, uint32_t rows, uint8_t* host)
+{
+    if (!c || !uniforms) return set_error(GAME_E_ARGUMENT, "game_hip_render: null argument");
+    if (rows == 0 || row0 + rows > c->h) return set_error(GAME_E_ARGUMENT, "game_hip_render: band outside the image");
+    if (nframes == 0) return GAME_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = upload_rows(c, uniforms, nframes);
+    if (rc) return rc;
+    const size_t frame_px = (size_t)c->w * c->h;
+    const size_t band_bytes = (size_t)rows * c->w * 4;
+    c->last_launches = 0;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (c->ir.uses_memory) {
+        // frame-serial: frame k reads the slot frame k-1 was written to
+        for (uint32_t f = 0; f < nframes; ++f) {
+            uint32_t slot = c->next_slot;
+            const uint32_t* prev = c->last_slot >= 0 ? c->frames + (size_t)c->last_slot * frame_px : nullptr;
+            rc = launch_frames(c, f, 1, slot, prev, row0, rows);
+            if (rc) return rc;
+            ++c->last_launches;
+            if (host)
+                HIP_TRY(hipMemcpyAsync(host + (size_t)f * band_bytes, c->frames + (size_t)slot * frame_px + (size_t)row0 * c->w,
+                                       band_bytes, hipMemcpyDeviceToHost, c->stream));
+            c->last_slot = (int)slot;
+            c->next_slot = (slot + 1) % c->ring;
+        }
+    } else {
+        uint32_t done = 0;
+        while (done < nframes) {
+            uint32_t chunk = nframes - done < c->ring ? nframes - done : c->ring;
+            uint32_t slot0 = c->next_slot;
+            rc = launch_frames(c, done, chunk, slot0, nullptr, row0, rows);
+            if (rc) return rc;
+            ++c->last_launches;
+            if (host)
+                for (uint32_t k = 0; k < chunk; ++k) {
+                    uint32_t slot = (slot0 + k) % c->ring;
+                    HIP_TRY(hipMemcpyAsync(host + (size_t)(done + k) * band_bytes,
+                                           c->frames + (size_t)slot * frame_px + (size_t)row0 * c->w, band_bytes,
+                                           hipMemcpyDeviceToHost, c->stream));
+                }
+            c->next_slot = (slot0 + chunk) % c->ring;
+            c->last_slot = (int)((slot0 + chunk - 1) % c->ring);
+            done += chunk;
+        }
+    }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    if (host) HIP_TRY(hipStreamSynchronize(c->stream));
+    return GAME_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int game_hip_device_count(int* count)
+{
+    if (!count) return set_error(GAME_E_ARGUMENT, "game_hip_device_count: null argument");
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) return hip_fail("hipGetDeviceCount", e);
+    return GAME_OK;
+}
+
+int game_hip_compile_only(const game_ir* ir, size_t* code_bytes)
+{
+    if (!ir) return set_error(GAME_E_ARGUMENT, "game_hip_compile_only: null ir");
+    std::vector<char> code;
+    std::string src = generate_frame_kernel(*ir->ir, shape_for(*ir->ir));
+    int rc = compile_hip(src, "game_frame.hip", code);
+    if (rc) return rc;
+    size_t total = code.size();
+    if (ir->ir->gravity.present) {
+        rc = compile_hip(generate_gravity_kernel(*ir->ir), "game_gravity.hip", code);
+        if (rc) return rc;
+        total += code.size();
+    }
+    if (code_bytes) *code_bytes = total;
+    return GAME_OK;
+}
+
+int game_hip_create(const game_ir* ir, uint32_t width, uint32_t height, int device, game_hip_ctx** out)
+{
+    if (!ir || !out) return set_error(GAME_E_ARGUMENT, "game_hip_create: null argument");
+    *out = nullptr;
+    if (width == 0 || height == 0 || width > 65536 || height > 65536)
+        return set_error(GAME_E_ARGUMENT, "game_hip_create: width/height must be in 1..65536");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return set_error(GAME_E_NO_DEVICE, std::string("game_hip_create: no HIP device available (") +
+                                               (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") + ")");
+    if (device < 0 || device >= ndev) return set_error(GAME_E_ARGUMENT, "game_hip_create: device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    auto* c = new game_hip_ctx;
+    c->ir = *ir->ir;
+    c->device = device;
+    c->w = width; c->h = height;
+    c->shape = shape_for(c->ir);
+    c->row_floats = BU_COUNT + (uint32_t)c->ir.uniforms.size();
+    c->ustride = c->row_floats + 2;
+    c->source = generate_frame_kernel(c->ir, c->shape);
+    std::vector<char> code;
+    int rc = compile_hip(c->source, "game_frame.hip", code);
+    if (rc) { delete c; return rc; }
+    auto fail = [&](const char* what, hipError_t err) { int r = hip_fail(what, err); game_hip_destroy(c); return r; };
+    if ((e = hipModuleLoadData(&c->mod, code.data())) != hipSuccess) return fail("hipModuleLoadData", e);
+    if ((e = hipModuleGetFunction(&c->fn, c->mod, "game_frame")) != hipSuccess) return fail("hipModuleGetFunction", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return fail("hipEventCreate", e);
+    rc = ensure_ring(c, c->ir.uses_memory ? 2u : 4u);
+    if (rc) { game_hip_destroy(c); return rc; }
+    if (c->ir.gravity.present) {
+        c->gsource = generate_gravity_kernel(c->ir);
+        rc = compile_hip(c->gsource, "game_gravity.hip", code);
+        if (rc) { game_hip_destroy(c); return rc; }
+        if ((e = hipModuleLoadData(&c->gmod, code.data())) != hipSuccess) return fail("hipModuleLoadData(gravity)", e);
+        if ((e = hipModuleGetFunction(&c->gfn, c->gmod, "game_gravity")) != hipSuccess) return fail("hipModuleGetFunction(gravity)", e);
+    }
+    *out = c;
+    return GAME_OK;
+}
+
+void game_hip_destroy(game_hip_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->frames) (void)hipFree(c->frames);
+    if (c->utab_dev) (void)hipFree(c->utab_dev);
+    for (int i = 0; i < 2; ++i) {
+        if (c->px[i]) (void)hipFree(c->px[i]);
+        if (c->py[i]) (void)hipFree(c->py[i]);
+    }
+    if (c->vx) (void)hipFree(c->vx);
+    if (c->vy) (void)hipFree(c->vy);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->mod) (void)hipModuleUnload(c->mod);
+    if (c->gmod) (void)hipModuleUnload(c->gmod);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int game_hip_set_ring(game_hip_ctx* c, uint32_t ring_frames)
+{
+    if (!c) return set_error(GAME_E_ARGUMENT, "game_hip_set_ring: null context");
+    if (ring_frames == 0 || (c->ir.uses_memory && ring_frames < 2))
+        return set_error(GAME_E_ARGUMENT, "game_hip_set_ring: ring needs >= 1 slot (>= 2 for memory cinematics)");
+    HIP_TRY(hipSetDevice(c->device));
+    return ensure_ring(c, ring_frames);
+}
+
+int game_hip_render(game_hip_ctx* c, const float* uniforms, uint32_t nframes, uint8_t* rgba8_host)
+{
+    if (!c) return set_error(GAME_E_ARGUMENT, "game_hip_render: null context");
+    return render_impl(c, uniforms, nframes, 0, c->h, rgba8_host);
+}
+
+int game_hip_render_band(game_hip_ctx* c, const float* uniforms, uint32_t nframes, uint32_t row0, uint32_t rows,
+                         uint8_t* rgba8_host)
+{
+    if (!c) return set_error(GAME_E_ARGUMENT, "game_hip_render_band: null context");
+    return render_impl(c, uniforms, nframes, row0, rows, rgba8_host);
+}
+
+int game_hip_reset_memory(game_hip_ctx* c)
+{
+    if (!c) return set_error(GAME_E_ARGUMENT, "game_hip_reset_memory: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    c->last_slot = -1;
+    c->next_slot = 0;
+    return GAME_OK;
+}
+
+int game_hip_sync(game_hip_ctx* c)
+{
+    if (!c) return set_error(GAME_E_ARGUMENT, "game_hip_sync: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GAME_OK;
+}
+
+void* game_hip_frame_ptr(game_hip_ctx* c, uint32_t slot)
+{
+    if (!c || slot >= c->ring) return nullptr;
+    return c->frames + (size_t)slot * c->w * c->h;
+}
+uint32_t game_hip_ring_frames(const game_hip_ctx* c) { return c ? c->ring : 0; }
+
+int game_hip_last_kernel_ms(game_hip_ctx* c, float* ms, uint32_t* launches)
+{
+    if (!c || !ms) return set_error(GAME_E_ARGUMENT, "game_hip_last_kernel_ms: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    if (launches) *launches = c->last_launches;
+    return GAME_OK;
+}
+
+const char* game_hip_kernel_source(const game_hip_ctx* c) { return c ? c->source.c_str() : ""; }
+
+// ── particles ────────────────────────────────────────────────────────────────────────────
+static int alloc_particles(game_hip_ctx* c, uint32_t n)
+{
+    if (c->n == n && c->px[0]) return GAME_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 2; ++i) {
+        if (c->px[i]) HIP_TRY(hipFree(c->px[i]));
+        if (c->py[i]) HIP_TRY(hipFree(c->py[i]));
+        c->px[i] = c->py[i] = nullptr;
+    }
+    if (c->vx) HIP_TRY(hipFree(c->vx));
+    if (c->vy) HIP_TRY(hipFree(c->vy));
+    c->vx = c->vy = nullptr;
+    size_t bytes = (size_t)n * 4;
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipMalloc((void**)&c->px[i], bytes));
+        HIP_TRY(hipMalloc((void**)&c->py[i], bytes));
+    }
+    HIP_TRY(hipMalloc((void**)&c->vx, bytes));
+    HIP_TRY(hipMalloc((void**)&c->vy, bytes));
+    c->n = n;
+    return GAME_OK;
+}
+
+int game_hip_particles_init(game_hip_ctx* c, uint32_t n, const float* pos_xy, const float* vel_xy)
+{
+    if (!c || !pos_xy || n == 0) return set_error(GAME_E_ARGUMENT, "game_hip_particles_init: bad argument");
+    if (!c->ir.gravity.present) return set_error(GAME_E_UNSUPPORTED, "cinematic has no gravity block");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = alloc_particles(c, n);
+    if (rc) return rc;
+    std::vector<float> x(n), y(n), vx(n, 0.0f), vy(n, 0.0f);
+    for (uint32_t i = 0; i < n; ++i) {
+        x[i] = pos_xy[2 * i]; y[i] = pos_xy[2 * i + 1];
+        if (vel_xy) { vx[i] = vel_xy[2 * i]; vy[i] = vel_xy[2 * i + 1]; }
+    }
+    size_t bytes = (size_t)n * 4;
+    c->cur = 0;
+    c->sim_time = 0.0f;
+    HIP_TRY(hipMemcpy(c->px[0], x.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->py[0], y.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->px[1], x.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->py[1], y.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->vx, vx.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->vy, vy.data(), bytes, hipMemcpyHostToDevice));
+    return GAME_OK;
+}
+
+int game_hip_particles_seed(game_hip_ctx* c, uint32_t n, uint64_t seed)
+{
+    if (!c || n == 0) return set_error(GAME_E_ARGUMENT, "game_hip_particles_seed: bad argument");
+    std::vector<float> pos((size_t)n * 2);
+    uint64_t s = seed;
+    for (size_t i = 0; i < (size_t)n * 2; ++i) {   // SplitMix64, top 24 bits -> [-1, 1)
+        s += 0x9E3779B97F4A7C15ull;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        pos[i] = (float)(z >> 40) * 0x1p-23f - 1.0f;
+    }
+    return game_hip_particles_init(c, n, pos.data(), nullptr);
+}
+
+int game_hip_particles_step(game_hip_ctx* c, float dt, uint32_t steps, uint32_t first, uint32_t count)
+{
+    if (!c) return set_error(GAME_E_ARGUMENT, "game_hip_particles_step: null context");
+    if (!c->gfn || !c->px[0]) return set_error(GAME_E_UNSUPPORTED, "particles not initialised (or no gravity block)");
+    if (count == 0 || first + count > c->n) return set_error(GAME_E_ARGUMENT, "game_hip_particles_step: range outside particle set");
+    if (count < c->n && steps > 1)
+        return set_error(GAME_E_ARGUMENT, "game_hip_particles_step: a partial range advances one step per call (exchange positions between steps)");
+    HIP_TRY(hipSetDevice(c->device));
+    c->last_launches = 0;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (uint32_t s = 0; s < steps; ++s) {
+        c->sim_time = c->sim_time + dt;   // `_time += dt` before the dispatch (gravity.rs:158)
+        GravityParams P;
+        P.xin = c->px[c->cur]; P.yin = c->py[c->cur];
+        P.xout = c->px[1 - c->cur]; P.yout = c->py[1 - c->cur];
+        P.vx = c->vx; P.vy = c->vy;
+        P.n = c->n; P.first = first; P.count = count; P.pad = 0;
+        P.dt = dt; P.time = c->sim_time;
+        void* args[] = {&P};
+        HIP_TRY(hipModuleLaunchKernel(c->gfn, (count + 255u) / 256u, 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+        ++c->last_launches;
+        c->cur = 1 - c->cur;
+    }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    return GAME_OK;
+}
+
+int game_hip_particles_read(game_hip_ctx* c, float* pos_xy, float* vel_xy)
+{
+    if (!c || !c->px[0]) return set_error(GAME_E_ARGUMENT, "game_hip_particles_read: particles not initialised");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<float> a(c->n), b(c->n);
+    size_t bytes = (size_t)c->n * 4;
+    if (pos_xy) {
+        HIP_TRY(hipMemcpy(a.data(), c->px[c->cur], bytes, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(b.data(), c->py[c->cur], bytes, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < c->n; ++i) { pos_xy[2 * i] = a[i]; pos_xy[2 * i + 1] = b[i]; }
+    }
+    if (vel_xy) {
+        HIP_TRY(hipMemcpy(a.data(), c->vx, bytes, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(b.data(), c->vy, bytes, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < c->n; ++i) { vel_xy[2 * i] = a[i]; vel_xy[2 * i + 1] = b[i]; }
+    }
+    return GAME_OK;
+}
+
+int game_hip_particles_positions(game_hip_ctx* c, float** x_dev, float** y_dev)
+{
+    if (!c || !c->px[0] || !x_dev || !y_dev) return set_error(GAME_E_ARGUMENT, "game_hip_particles_positions: bad argument");
+    *x_dev = c->px[c->cur];
+    *y_dev = c->py[c->cur];
+    return GAME_OK;
+}
+
+int game_hip_particles_time(game_hip_ctx* c, float* sim_time)
+{
+    if (!c || !sim_time) return set_error(GAME_E_ARGUMENT, "game_hip_particles_time: bad argument");
+    *sim_time = c->sim_time;
+    return GAME_OK;
+}
+
+}  // extern "C"

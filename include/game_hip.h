@@ -158,6 +158,18 @@ int game_hip_particles_read(game_hip_ctx* ctx, float* pos_xy_host, float* vel_xy
 int game_hip_particles_positions(game_hip_ctx* ctx, float** x_dev, float** y_dev);
 int game_hip_particles_time(game_hip_ctx* ctx, float* sim_time);
 
+/* ── diagnostics (no counterpart in the reference) ─────────────────────────────────────────
+ * Element-wise evaluation of the device math / noise functions on host arrays, so that tests can
+ * compare them bit-for-bit with a CPU restatement. op: 0 fract, 1 sin, 2 cos, 3 atan2(a,b),
+ * 4 hash2(a,b), 5 noise2(a,b), 6 simplex2d(a,b), 7 voronoi2d(a,b,5), 8 exp2, 9 log2, 10 pow(a,b),
+ * 11 max(a,b), 12 min(a,b), 13 fbm2(a,b,6,.5,2), 14 sqrt, 15 a/b, 16 smoothstep(.005,-.005,a),
+ * 17 mod(a,b). b may be NULL for one-argument ops. */
+int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out);
+/* Exhaustive check, over all 2^32 float bit patterns, that the hardware instruction equals its
+ * defining formula: which 0 = v_fract_f32 vs min(x - floor(x), 1 - 2^-24); 1 / 2 = v_max_f32 /
+ * v_min_f32 vs "NaN yields the other operand, -0 < +0" against probe constants. */
+int game_hip_check_exhaustive(int which, uint64_t* mismatches, uint32_t* first_bad);
+
 #ifdef __cplusplus
 }
 #endif
