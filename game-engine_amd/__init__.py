@@ -43,6 +43,8 @@ def _load():
         "game_program_warning_count": (sz, [vp]),
         "game_program_warning": (c.c_char_p, [vp, sz]),
         "game_front_lex": (c.c_int, [c.c_char_p, sz, c.POINTER(sz), vp, sz]),
+        "game_front_tokens": (c.c_char_p, [c.c_char_p, sz]),
+        "game_front_ast_json": (c.c_char_p, [c.c_char_p, sz, c.c_int]),
         "game_builtin_count": (sz, []),
         "game_builtin_describe": (c.c_char_p, [sz]),
         "game_ir_name": (c.c_char_p, [vp]),
@@ -195,6 +197,32 @@ def lex(source):
     spans = (ctypes.c_size_t * (2 * max(n.value, 1)))()
     _check(lib.game_front_lex(source, len(source), ctypes.byref(n), spans, n.value))
     return [(spans[2 * i], spans[2 * i + 1]) for i in range(n.value)]
+
+
+def tokens(source):
+    """[(start, end, display text)] per token (reference: lexer::lex + Token's Display)."""
+    if isinstance(source, str):
+        source = source.encode("utf-8")
+    n = ctypes.c_size_t()
+    _check(lib.game_front_lex(source, len(source), ctypes.byref(n), None, 0))
+    r = lib.game_front_tokens(source, len(source))
+    out = []
+    for rec in r.decode("utf-8").split("\x1e"):
+        if rec:
+            a, b, text = rec.split("\x1f", 2)
+            out.append((int(a), int(b), text))
+    return out
+
+
+def parse(source, optimized=False):
+    """AST as a dict (reference: game_compiler::compile_to_ast); optimized=True also runs
+    expand_defines + optimize_cinematic."""
+    if isinstance(source, str):
+        source = source.encode("utf-8")
+    r = lib.game_front_ast_json(source, len(source), 1 if optimized else 0)
+    if r is None:
+        raise GameError(3, lib.game_last_error().decode("utf-8", "replace"))
+    return json.loads(r.decode("utf-8"))
 
 
 def list_builtins():

@@ -70,8 +70,12 @@ int game_front_lex(const char* src, size_t len, size_t* ntokens, size_t* spans, 
 {
     if (!src || !ntokens) return set_error(GAME_E_ARGUMENT, "game_front_lex: null argument");
     std::vector<Token> toks;
-    CompileError e = lex(std::string(src, len), toks);
-    if (!e.ok()) return set_error(error_code_of(e), e.display());
+    std::string source(src, len);
+    CompileError e = lex(source, toks);
+    if (!e.ok()) {
+        g_last_rendered = e.render_with_source(source);
+        return set_error(error_code_of(e), e.display());
+    }
     *ntokens = toks.size();
     if (spans)
         for (size_t i = 0; i < toks.size() && i < cap; ++i) { spans[2 * i] = toks[i].start; spans[2 * i + 1] = toks[i].end; }

@@ -62,6 +62,13 @@ const char* game_last_error_rendered(void);
 
 /* game_compiler::lex (lib.rs:76): number of tokens, and per token its byte span and display text. */
 int game_front_lex(const char* src, size_t len, size_t* ntokens, size_t* spans /* 2*cap */, size_t cap);
+/* Token records "<start>\x1f<end>\x1f<display>" separated by \x1e, with the display text of
+ * token.rs:82-149 (keywords and punctuation as written, numbers in shortest form, units
+ * re-attached). NULL on a lex error. Thread-local storage, valid until the next call. */
+const char* game_front_tokens(const char* src, size_t len);
+/* game_compiler::compile_to_ast (lib.rs:66) as JSON: stage 0 = as parsed; stage 1 = after
+ * expand_defines + optimize_cinematic (lib.rs:121-129). NULL on a lex/parse error. */
+const char* game_front_ast_json(const char* src, size_t len, int stage);
 /* game_compiler::list_builtins (lib.rs:102): "name|Input|Output|param,param,..." per builtin. */
 size_t game_builtin_count(void);
 const char* game_builtin_describe(size_t index);

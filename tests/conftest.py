@@ -21,7 +21,8 @@ def load_product():
     if "game_engine_amd" in sys.modules:
         return sys.modules["game_engine_amd"]
     path = os.path.join(ROOT, "game-engine_amd", "__init__.py")
-    spec = importlib.util.spec_from_file_location("game_engine_amd", path)
+    spec = importlib.util.spec_from_file_location("game_engine_amd", path,
+                                                  submodule_search_locations=[os.path.dirname(path)])
     mod = importlib.util.module_from_spec(spec)
     sys.modules["game_engine_amd"] = mod
     spec.loader.exec_module(mod)

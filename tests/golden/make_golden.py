@@ -1,0 +1,36 @@
+"""Regenerates the regression fixtures in this directory from the CPU oracle.
+
+These are NOT reference outputs: the reference cannot execute pixels and ships no golden images.
+They pin the oracle against accidental change; run from the repository root:
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import conftest as T  # noqa: E402
+from gallery import GALLERY  # noqa: E402
+from test_oracle import GOLDEN_CASES  # noqa: E402
+
+game = T.load_product()
+oracle = T.Oracle()
+
+
+def frame(src, w, h, t, audio):
+    cin = game.compile(src).cinematics[0]
+    rows = cin.uniform_rows([t], w, h, audio=audio)
+    return oracle.render(cin.blob, w, h, rows[0], threads=4)
+
+
+for name, (src, w, h, t, audio) in GOLDEN_CASES.items():
+    np.save(os.path.join(HERE, name + ".npy"), frame(src, w, h, t, audio))
+np.savez_compressed(os.path.join(HERE, "gallery.npz"),
+                    **{n: frame(s, 48, 27, 2.5, {"bass": 0.7, "mid": 0.2, "treble": 0.9}) for n, s in GALLERY.items()})
+src = 'cinematic "t" { gravity { rule: 0.01 / (dist * dist + 0.01) * sin(time * 3.0 + 1.0), damping: 0.98, bounds: wrap } layer s { circle() | glow() } }'
+cin = game.compile(src).cinematics[0]
+p, _ = oracle.gravity(cin.blob, oracle.seed_particles(257), 1 / 60, 5, threads=4)
+np.save(os.path.join(HERE, "gravity_257.npy"), p)
+print("wrote goldens to", HERE)

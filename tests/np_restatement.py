@@ -1,0 +1,136 @@
+"""Independent numpy (float32, one rounding per operation) restatement of the parts of the emitted
+GLSL that use no transcendental function, written from game-compiler/src/codegen/glsl.rs without
+looking at the C oracle's structure. Used to cross-check oracle/game_oracle.c bit for bit; numpy
+float32 arithmetic is IEEE single precision with no fused operations.
+"""
+import numpy as np
+
+F = np.float32
+
+
+def f(x):
+    return np.asarray(x, dtype=np.float32)
+
+
+def fract(x):
+    r = x - np.floor(x)
+    return np.where(r < F(1.0), r, F(np.nextafter(np.float32(1.0), np.float32(0.0)))).astype(np.float32)
+
+
+def mix(a, b, t):
+    return a * (F(1.0) - t) + b * t
+
+
+def clamp(x, lo, hi):
+    return np.minimum(np.maximum(x, F(lo)), F(hi))
+
+
+def smoothstep(e0, e1, x):
+    t = clamp((x - F(e0)) / (F(e1) - F(e0)), 0.0, 1.0)
+    return t * t * (F(3.0) - F(2.0) * t)
+
+
+def hash2(px, py):  # glsl.rs:134-138
+    x = fract(px * F(0.1031))
+    y = fract(py * F(0.1031))
+    z = fract(px * F(0.1031))
+    d = x * (y + F(33.33)) + y * (z + F(33.33)) + z * (x + F(33.33))
+    x, y, z = x + d, y + d, z + d
+    return fract((x + y) * z)
+
+
+def noise2(px, py):  # glsl.rs:141-150
+    ix, iy = np.floor(px), np.floor(py)
+    fx, fy = fract(px), fract(py)
+    ux = fx * fx * (F(3.0) - F(2.0) * fx)
+    uy = fy * fy * (F(3.0) - F(2.0) * fy)
+    a = hash2(ix, iy)
+    b = hash2(ix + F(1.0), iy + F(0.0))
+    c = hash2(ix + F(0.0), iy + F(1.0))
+    d = hash2(ix + F(1.0), iy + F(1.0))
+    return mix(mix(a, b, ux), mix(c, d, ux), uy) * F(2.0) - F(1.0)
+
+
+def fbm2(px, py, octaves, persistence, lacunarity):  # glsl.rs:155-169
+    value = np.zeros_like(px)
+    amplitude, frequency, max_val = F(1.0), F(1.0), F(0.0)
+    qx, qy = px, py
+    for _ in range(octaves):
+        value = value + noise2(qx * frequency, qy * frequency) * amplitude
+        max_val = F(max_val + amplitude)
+        amplitude = F(amplitude * F(persistence))
+        frequency = F(frequency * F(lacunarity))
+        qx, qy = qx * F(0.8) - qy * F(0.6), qx * F(0.6) + qy * F(0.8)
+    return value / max_val
+
+
+def apply_glow(d, intensity):  # glsl.rs:102-107
+    i = F(intensity)
+    core = smoothstep(0.005, -0.005, d)
+    md = np.maximum(d, F(0.0))
+    halo = i / (F(1.0) + md * md * i * i * F(16.0))
+    return core + halo
+
+
+def pixel_grid(w, h):
+    """uv per pixel, top row first: v_uv = ((i + .5)/W, (j + .5)/H) with j counted from the bottom."""
+    inv_w, inv_h = F(1.0) / F(w), F(1.0) / F(h)
+    x = (np.arange(w, dtype=np.float32) + F(0.5)) * inv_w
+    y = (np.arange(h - 1, -1, -1, dtype=np.float32) + F(0.5)) * inv_h
+    uvx = np.broadcast_to(x * F(2.0) - F(1.0), (h, w)).astype(np.float32)
+    uvy = np.broadcast_to((y * F(2.0) - F(1.0))[:, None], (h, w)).astype(np.float32)
+    return uvx, uvy
+
+
+def pack(r, g, b, a):
+    def u8(c):
+        c = np.where(np.isnan(c), F(0.0), c)
+        t = np.minimum(np.maximum(c, F(0.0)), F(1.0))
+        return (t * F(255.0) + F(0.5)).astype(np.uint32).astype(np.uint8)
+    return np.stack([u8(r), u8(g), u8(b), u8(np.broadcast_to(f(a), r.shape))], axis=-1)
+
+
+def render_c1(w, h):
+    """circle(0.3) | glow(2.0) | tint(0.831, 0.686, 0.216)"""
+    uvx, uvy = pixel_grid(w, h)
+    aspect = F(w) / F(h)
+    px, py = uvx * aspect, uvy
+    sdf = np.sqrt(px * px + py * py) - F(0.3)
+    g = apply_glow(sdf, 2.0)
+    return pack(g * F(0.831), g * F(0.686), g * F(0.216), 1.0)
+
+
+def render_c2(w, h):
+    """domain_warp(0.1, 3.0) | fbm(3.0, 6, 0.5, 2.0) | glow(1.5) | tint(0.686, 0.878, 0.953)"""
+    uvx, uvy = pixel_grid(w, h)
+    aspect = F(w) / F(h)
+    px, py = uvx * aspect, uvy
+    n0 = noise2(px * F(3.0), py * F(3.0))
+    n1 = noise2(px * F(3.0) + F(5.2), py * F(3.0) + F(1.3))
+    px, py = px + n0 * F(0.1), py + n1 * F(0.1)
+    sdf = fbm2(px * F(3.0), py * F(3.0), 6, 0.5, 2.0)
+    g = apply_glow(sdf, 1.5)
+    return pack(g * F(0.686), g * F(0.878), g * F(0.953), 1.0)
+
+
+def render_c3_no_grain(w, h, bass, mid, treble):
+    """spectrum(0,0,0) | bloom(0.4, 2.0) | chromatic(0.6) | vignette(0.35) with audio uniforms."""
+    uvx, uvy = pixel_grid(w, h)
+    sx = uvx * F(0.5) + F(0.5)
+    r = smoothstep(0.0, 0.33, sx) * (F(bass) + F(0.0))
+    g = smoothstep(0.33, 0.66, sx) * (F(mid) + F(0.0))
+    b = smoothstep(0.66, 1.0, sx) * (F(treble) + F(0.0))
+    lum = r * F(0.299) + g * F(0.587) + b * F(0.114)
+    add = np.maximum(lum - F(0.4), F(0.0)) * F(2.0)
+    r, g, b = r + add, g + add, b + add
+    ln = np.sqrt(uvx * uvx + uvy * uvy)
+    dirx = uvx / ln * F(0.6)
+    r, b = r * (F(1.0) + dirx), b * (F(1.0) - dirx)
+    fac = F(1.0) - smoothstep(0.8, F(0.8) + F(0.35), ln)
+    return pack(r * fac, g * fac, b * fac, 1.0)
+
+
+def memory_mix(cur_rgba_float, prev_rgba8, decay):
+    """memory.rs:38-45 on float colours; prev is RGBA8."""
+    prev = prev_rgba8.astype(np.float32) / F(255.0)
+    return mix(cur_rgba_float, prev, F(decay))

@@ -1,0 +1,86 @@
+"""CPU checks of the boundary: the shared library exports every symbol include/game_hip.h
+declares, fails loudly without a GPU, and its kernel generator produces gfx950 code objects."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import C1_HELLO, C2_FBM, C2B_NOISE, C3_SHOWCASE, C4_TRAILS, C5_GRAVITY, ROOT
+from gallery import GALLERY
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "game_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(game_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(game):
+    lib = ctypes.CDLL(game.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 45
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/game_hip.h but not exported"
+    assert set(game.EXPORTED_SYMBOLS) == set(names)     # the binding covers the whole header
+
+
+def test_library_is_the_in_tree_build(game):
+    assert game.LIB_PATH.startswith(ROOT) and os.path.exists(game.LIB_PATH)
+
+
+@pytest.mark.parametrize("src", [C1_HELLO, C2_FBM, C2B_NOISE, C3_SHOWCASE, C4_TRAILS, C5_GRAVITY], ids=["c1", "c2", "c2b", "c3", "c4", "c5"])
+def test_benchmark_kernels_compile_for_gfx950(game, src):
+    assert game.compile(src).cinematics[0].compile_only() > 1000
+
+
+def test_gallery_kernels_compile_for_gfx950(game):
+    for name, src in GALLERY.items():
+        assert game.compile(src).cinematics[0].compile_only() > 1000, name
+
+
+def test_gpu_entry_points_fail_loudly_without_a_device(game):
+    """No silent CPU fallback: on a machine without a GPU the render path raises."""
+    try:
+        n = game.device_count()
+    except game.GameError:
+        n = 0
+    if n > 0:
+        pytest.skip("a GPU is present")
+    cin = game.compile(C1_HELLO).cinematics[0]
+    with pytest.raises(game.GameError) as ei:
+        cin.renderer(64, 64)
+    assert ei.value.code in (81, 82)
+    with pytest.raises(game.GameError):
+        game.device_eval("sin", np.zeros(4, np.float32))
+
+
+def test_product_does_not_touch_the_oracle():
+    """The shipped path must not import, link or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "game-engine_amd")
+    for d, _, files in os.walk(pkg):
+        if os.path.basename(d) == "build":
+            continue
+        for f in files:
+            if f.endswith((".cpp", ".hpp", ".h", ".hip", ".py", ".inc")) or f == "Makefile":
+                assert "oracle" not in open(os.path.join(d, f), errors="replace").read().lower(), os.path.join(d, f)
+    out = os.popen("ldd '%s'" % os.path.join(pkg, "libgame_hip.so")).read()
+    assert "oracle" not in out
+
+
+def test_default_uniform_rows(game):
+    cin = game.compile(C3_SHOWCASE).cinematics[0]
+    rows = cin.uniform_rows([0.0, 1.5], 3840, 2160, audio={"bass": 0.8}, user={"mid": [0.1, 0.2]})
+    assert rows.shape == (2, 13)
+    assert rows[1, 0] == 1.5 and rows[0, 1] == np.float32(0.8) and tuple(rows[0, 6:10]) == (3840.0, 2160.0, 0.0, 0.0)
+    assert rows[1, 10 + 1] == np.float32(0.2) and rows[0, 10] == 0.0
+
+
+def test_blob_header(game):
+    cin = game.compile(C4_TRAILS).cinematics[0]
+    h = game.parse_blob(cin.blob)
+    assert h["magic"] == 0x31524947 and h["total"] == len(cin.blob) and h["name"] == "trails"
+    assert (h["n_layers"], h["n_stages"], h["uses_memory"], h["multi_layer"]) == (1, 4, 1, 0)
+    g = game.parse_blob(game.compile(C5_GRAVITY).cinematics[0].blob)
+    assert g["gravity_present"] == 1 and g["damping"] == np.float32(0.995) and g["bounds"] == 0
