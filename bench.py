@@ -84,7 +84,7 @@ def cpu_baseline_frames(game, oracle, cin, cfg, seconds_budget=20.0):
     t0 = time.time()
     oracle.render(cin.blob, w, h, rows[0], row0=0, rows=probe_rows, threads=threads)
     per_row = (time.time() - t0) / probe_rows
-    nrows = int(min(h * 4, max(threads, seconds_budget / max(per_row, 1e-9))))
+    nrows = int(max(threads, seconds_budget / max(per_row, 1e-9)))
     done, t0 = 0, time.time()
     while done < nrows:
         n = min(h, nrows - done)

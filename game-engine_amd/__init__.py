@@ -71,6 +71,7 @@ def _load():
         "game_hip_last_kernel_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(u32)]),
         "game_hip_kernel_source": (c.c_char_p, [vp]),
         "game_hip_compile_only": (c.c_int, [vp, c.POINTER(sz)]),
+        "game_hip_dump_code": (c.c_int, [vp, c.c_char_p]),
         "game_hip_particles_init": (c.c_int, [vp, u32, vp, vp]),
         "game_hip_particles_seed": (c.c_int, [vp, u32, u64]),
         "game_hip_particles_step": (c.c_int, [vp, f32, u32, u32, u32]),
@@ -159,6 +160,10 @@ class Cinematic:
         n = ctypes.c_size_t()
         _check(lib.game_hip_compile_only(self._h, ctypes.byref(n)))
         return n.value
+
+    def dump_code(self, path_prefix):
+        """Writes the generated kernel source and gfx950 code object next to `path_prefix`."""
+        _check(lib.game_hip_dump_code(self._h, path_prefix.encode()))
 
     def renderer(self, w, h, device=0):
         return Renderer(self, w, h, device)

@@ -142,12 +142,12 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     k += "    const float aspect = U[" + std::to_string(shape.aspect_slot) + "];\n";
     k += "    s.bass = U[1]; s.mid = U[2]; s.treble = U[3];\n";
     k += "    const float vy = ((float)(P.h - 1u - ty) + 0.5f) * P.inv_h;\n";   // GL row 0 is the bottom row
-    k += "    s.uvy = vy * 2.0f - 1.0f;\n";
+    k += "#ifdef GD_FMA_UV\n    s.uvy = __builtin_fmaf(vy, 2.0f, -1.0f);\n#else\n    s.uvy = vy * 2.0f - 1.0f;\n#endif\n";
     if (shape.pixels_per_lane > 1) k += "#pragma unroll 1\n    for (gd_u32 kx = 0; kx < " + std::to_string(shape.pixels_per_lane) + "u; ++kx) {\n    const gd_u32 x = x0 + kx;\n";
     else k += "    {\n    const gd_u32 x = x0;\n";
     k += "    if (x < P.w) {\n";
     k += "    const float vx = ((float)x + 0.5f) * P.inv_w;\n";
-    k += "    s.uvx = vx * 2.0f - 1.0f;\n";
+    k += "#ifdef GD_FMA_UV\n    s.uvx = __builtin_fmaf(vx, 2.0f, -1.0f);\n#else\n    s.uvx = vx * 2.0f - 1.0f;\n#endif\n";
     if (ir.uses_memory)
         k += "    const gd_u32 prev = P.prev ? P.prev[(unsigned long long)ty * P.w + x] : 0u;\n";
     if (ir.multi_layer) k += "    float fr = 0.0f, fg = 0.0f, fb = 0.0f, fa = 1.0f;\n";

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -89,8 +91,21 @@ int compile_hip(const std::string& src, const char* name, std::vector<char>& cod
     hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), name, 1, hdr_src, hdr_name);
     if (r != HIPRTC_SUCCESS) return set_error(GAME_E_HIP, std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r));
     // One rounding per source operator: contraction off; fma only where the source says fma.
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
-    r = hiprtcCompileProgram(prog, 4, opts);
+    std::vector<std::string> flags = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+    // Tuning hook: extra hiprtc options, space separated (later options override earlier ones).
+    if (const char* extra = getenv("GAME_HIP_FLAGS")) {
+        std::string e(extra);
+        size_t i = 0;
+        while (i < e.size()) {
+            size_t j = e.find(' ', i);
+            if (j == std::string::npos) j = e.size();
+            if (j > i) flags.push_back(e.substr(i, j - i));
+            i = j + 1;
+        }
+    }
+    std::vector<const char*> opts;
+    for (const std::string& f : flags) opts.push_back(f.c_str());
+    r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
         hiprtcGetProgramLogSize(prog, &n);
@@ -174,7 +189,9 @@ int launch_frames(game_hip_ctx* c, uint32_t frame0, uint32_t count, uint32_t slo
     void* args[] = {&P};
     uint32_t gx = (c->w + 32u * c->shape.pixels_per_lane - 1u) / (32u * c->shape.pixels_per_lane);
     uint32_t gy = (rows + 7u) / 8u;
-    HIP_TRY(hipModuleLaunchKernel(c->fn, gx, gy, count, 256, 1, 1, 0, c->stream, args, nullptr));
+    // Tuning hook: dynamic LDS request per workgroup, to cap resident workgroups per CU.
+    static const unsigned lds_bytes = getenv("GAME_HIP_LDS_BYTES") ? (unsigned)atoi(getenv("GAME_HIP_LDS_BYTES")) : 0u;
+    HIP_TRY(hipModuleLaunchKernel(c->fn, gx, gy, count, 256, 1, 1, lds_bytes, c->stream, args, nullptr));
     return GAME_OK;
 }
 
@@ -256,6 +273,33 @@ int game_hip_compile_only(const game_ir* ir, size_t* code_bytes)
         total += code.size();
     }
     if (code_bytes) *code_bytes = total;
+    return GAME_OK;
+}
+
+int game_hip_dump_code(const game_ir* ir, const char* path_prefix)
+{
+    if (!ir || !path_prefix) return set_error(GAME_E_ARGUMENT, "game_hip_dump_code: null argument");
+    auto write = [&](const std::string& path, const void* data, size_t n) {
+        FILE* f = fopen(path.c_str(), "wb");
+        if (!f) return false;
+        bool ok = fwrite(data, 1, n, f) == n;
+        fclose(f);
+        return ok;
+    };
+    std::vector<char> code;
+    std::string src = generate_frame_kernel(*ir->ir, shape_for(*ir->ir));
+    int rc = compile_hip(src, "game_frame.hip", code);
+    if (rc) return rc;
+    std::string pre(path_prefix);
+    if (!write(pre + "_frame.hip", src.data(), src.size()) || !write(pre + "_frame.co", code.data(), code.size()))
+        return set_error(GAME_E_ARGUMENT, "game_hip_dump_code: cannot write " + pre + "_frame.*");
+    if (ir->ir->gravity.present) {
+        src = generate_gravity_kernel(*ir->ir);
+        rc = compile_hip(src, "game_gravity.hip", code);
+        if (rc) return rc;
+        if (!write(pre + "_gravity.hip", src.data(), src.size()) || !write(pre + "_gravity.co", code.data(), code.size()))
+            return set_error(GAME_E_ARGUMENT, "game_hip_dump_code: cannot write " + pre + "_gravity.*");
+    }
     return GAME_OK;
 }
 

@@ -150,6 +150,9 @@ int game_hip_last_kernel_ms(game_hip_ctx* ctx, float* ms, uint32_t* launches);
 const char* game_hip_kernel_source(const game_hip_ctx* ctx);
 /* Compile the generated kernel for gfx950 without touching a device (build-time check). */
 int game_hip_compile_only(const game_ir* ir, size_t* code_bytes);
+/* Same, and writes <prefix>_frame.hip / <prefix>_frame.co (and _gravity.*): the generated source
+ * and the gfx950 code object, for disassembly and instruction-mix studies. */
+int game_hip_dump_code(const game_ir* ir, const char* path_prefix);
 
 /* ── gravity particles ─────────────────────────────────────────────────────────────────────
  * Replaces GameGravitySim.init/dispatch (game-compiler/src/codegen/gravity.rs:123-191) and the
