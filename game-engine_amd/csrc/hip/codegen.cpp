@@ -129,25 +129,28 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
          "};\n\n";
     k += "extern \"C\" __global__ __launch_bounds__(256) void game_frame(GameFrameParams P)\n{\n";
     // wave64 tile = 8x8 pixels; a 256-thread workgroup covers 32x8 (4 waves side by side)
+    k += "#ifdef GD_PAD\n    for (int pad = 0; pad < GD_PAD; ++pad) asm volatile(\"s_nop 0\");\n#endif\n";
     k += "    const gd_u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;\n";
     k += "    const gd_u32 x0 = (blockIdx.x * 32u + wave * 8u + (lane & 7u)) * " + std::to_string(shape.pixels_per_lane) + "u;\n";
     k += "    const gd_u32 ty = P.row0 + blockIdx.y * 8u + (lane >> 3);\n";
     k += "    if (ty >= P.row0 + P.rows) return;\n";
     k += "    const gd_u32 fidx = blockIdx.z;\n";
     k += "    const float* __restrict__ U = P.utab + (unsigned long long)(P.frame0 + fidx) * P.ustride;\n";
-    k += "    const gd_u32 slot = (P.slot0 + fidx) % P.ring;\n";
+    // slot0 < ring and fidx < ring (checked by the host), so one conditional subtract wraps the ring
+    k += "    const gd_u32 slot_raw = P.slot0 + fidx;\n";
+    k += "    const gd_u32 slot = slot_raw >= P.ring ? slot_raw - P.ring : slot_raw;\n";
     k += "    gd_u32* __restrict__ dst = P.out + (unsigned long long)slot * P.frame_pixels + (unsigned long long)ty * P.w;\n";
     k += "    GdPix s;\n";
     k += "    s.time = U[" + std::to_string(shape.time_slot) + "];\n";
     k += "    const float aspect = U[" + std::to_string(shape.aspect_slot) + "];\n";
     k += "    s.bass = U[1]; s.mid = U[2]; s.treble = U[3];\n";
     k += "    const float vy = ((float)(P.h - 1u - ty) + 0.5f) * P.inv_h;\n";   // GL row 0 is the bottom row
-    k += "#ifdef GD_FMA_UV\n    s.uvy = __builtin_fmaf(vy, 2.0f, -1.0f);\n#else\n    s.uvy = vy * 2.0f - 1.0f;\n#endif\n";
+    k += "    s.uvy = vy * 2.0f - 1.0f;\n";
     if (shape.pixels_per_lane > 1) k += "#pragma unroll 1\n    for (gd_u32 kx = 0; kx < " + std::to_string(shape.pixels_per_lane) + "u; ++kx) {\n    const gd_u32 x = x0 + kx;\n";
     else k += "    {\n    const gd_u32 x = x0;\n";
     k += "    if (x < P.w) {\n";
     k += "    const float vx = ((float)x + 0.5f) * P.inv_w;\n";
-    k += "#ifdef GD_FMA_UV\n    s.uvx = __builtin_fmaf(vx, 2.0f, -1.0f);\n#else\n    s.uvx = vx * 2.0f - 1.0f;\n#endif\n";
+    k += "    s.uvx = vx * 2.0f - 1.0f;\n";
     if (ir.uses_memory)
         k += "    const gd_u32 prev = P.prev ? P.prev[(unsigned long long)ty * P.w + x] : 0u;\n";
     if (ir.multi_layer) k += "    float fr = 0.0f, fg = 0.0f, fb = 0.0f, fa = 1.0f;\n";

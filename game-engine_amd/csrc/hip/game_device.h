@@ -27,25 +27,13 @@ GD float gd_sqrt(float x) { return __builtin_sqrtf(x); }             // correctl
 GD float gd_fract(float x) { return __builtin_amdgcn_fractf(x); }
 GD float gd_mod(float x, float y) { return x - y * gd_floor(x / y); }
 GD float gd_step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
-#ifdef GD_FMA_MIX
 GD float gd_mix(float a, float b, float t) { return __builtin_fmaf(b, t, a * (1.0f - t)); }
-#else
-GD float gd_mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
-#endif
 GD float gd_smoothstep(float e0, float e1, float x)
 {
     float t = gd_clamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
-#ifdef GD_FMA_SS
     return t * t * __builtin_fmaf(-2.0f, t, 3.0f);
-#else
-    return t * t * (3.0f - 2.0f * t);
-#endif
 }
-#ifdef GD_FMA_LEN
 GD float gd_length2(float x, float y) { return gd_sqrt(__builtin_fmaf(x, x, y * y)); }
-#else
-GD float gd_length2(float x, float y) { return gd_sqrt(x * x + y * y); }
-#endif
 
 // ── sin / cos / atan ────────────────────────────────────────────────────────────────────
 // GLSL does not fix the precision of these; the render path uses a fixed algorithm made of
@@ -160,9 +148,6 @@ GD float gd_log(float x) { return gd_log2(x) * 0.69314718055994530942f; }
 // because p3.x == p3.z; the sum is evaluated left to right exactly as dot() is written.
 GD float gd_hash2(float px, float py)
 {
-#ifdef GD_HASH_STRICT
-#pragma clang fp contract(off)
-#endif
     float x = gd_fract(px * 0.1031f);
     float y = gd_fract(py * 0.1031f);
     float z = x;
@@ -176,22 +161,13 @@ GD float gd_noise2(float px, float py)
 {
     float ix = gd_floor(px), iy = gd_floor(py);
     float fx = gd_fract(px), fy = gd_fract(py);
-#ifdef GD_FMA_SMOOTH
     float ux = fx * fx * __builtin_fmaf(-2.0f, fx, 3.0f);
     float uy = fy * fy * __builtin_fmaf(-2.0f, fy, 3.0f);
-#else
-    float ux = fx * fx * (3.0f - 2.0f * fx);
-    float uy = fy * fy * (3.0f - 2.0f * fy);
-#endif
     float a = gd_hash2(ix, iy);
     float b = gd_hash2(ix + 1.0f, iy);
     float c = gd_hash2(ix, iy + 1.0f);
     float d = gd_hash2(ix + 1.0f, iy + 1.0f);
-#ifdef GD_FMA_REMAP
     return __builtin_fmaf(gd_mix(gd_mix(a, b, ux), gd_mix(c, d, ux), uy), 2.0f, -1.0f);
-#else
-    return gd_mix(gd_mix(a, b, ux), gd_mix(c, d, ux), uy) * 2.0f - 1.0f;
-#endif
 }
 
 GD int gd_octaves(float o)   // int(x), clamped to [0, 32]
@@ -209,21 +185,12 @@ GD float gd_fbm2(float px, float py, int octaves, float persistence, float lacun
     float qx = px, qy = py;
 #pragma unroll
     for (int i = 0; i < octaves; i++) {
-#ifdef GD_FMA_FBM
         value = __builtin_fmaf(gd_noise2(qx * frequency, qy * frequency), amplitude, value);
-#else
-        value = value + gd_noise2(qx * frequency, qy * frequency) * amplitude;
-#endif
         max_val = max_val + amplitude;
         amplitude = amplitude * persistence;
         frequency = frequency * lacunarity;
-#ifdef GD_FMA_FBM
         float nx = __builtin_fmaf(qx, 0.8f, -(qy * 0.6f));
         float ny = __builtin_fmaf(qx, 0.6f, qy * 0.8f);
-#else
-        float nx = qx * 0.8f - qy * 0.6f;
-        float ny = qx * 0.6f + qy * 0.8f;
-#endif
         qx = nx; qy = ny;
     }
     return value / max_val;
@@ -289,11 +256,7 @@ GD float gd_voronoi2d(float px, float py, float scale)   // glsl.rs:202-219
 GD float gd_apply_glow(float d, float intensity)   // glsl.rs:102-107
 {
     float core = gd_smoothstep(0.005f, -0.005f, d);
-#ifdef GD_FMA_GLOW
     float halo = intensity / __builtin_fmaf(gd_max(d, 0.0f) * gd_max(d, 0.0f) * intensity * intensity, 16.0f, 1.0f);
-#else
-    float halo = intensity / (1.0f + gd_max(d, 0.0f) * gd_max(d, 0.0f) * intensity * intensity * 16.0f);
-#endif
     return core + halo;
 }
 
@@ -388,13 +351,8 @@ GD void gb_repeat(GdPix& s, float count)                                        
 GD void gb_domain_warp(GdPix& s, float amount, float freq)                                              // :362-366
 {
     float n0 = gd_noise2(s.px * freq, s.py * freq);
-#ifdef GD_FMA_WARP
-    float n1 = gd_noise2(__builtin_fmaf(s.px, freq, 5.2f), __builtin_fmaf(s.py, freq, 1.3f));
-    s.px = __builtin_fmaf(n0, amount, s.px); s.py = __builtin_fmaf(n1, amount, s.py);
-#else
     float n1 = gd_noise2(s.px * freq + 5.2f, s.py * freq + 1.3f);
     s.px = s.px + n0 * amount; s.py = s.py + n1 * amount;
-#endif
 }
 GD void gb_curl_noise(GdPix& s, float frequency, float amplitude)                                       // :367-377
 {
@@ -521,11 +479,7 @@ GD void gb_memory_mix(GdPix& s, gd_u32 prev, float decay)
 }
 
 // Framebuffer write: RGBA8 unorm, round(clamp(c, 0, 1) * 255), R in the low byte.
-#ifdef GD_FMA_PACK
 GD gd_u32 gd_unorm8(float c) { return (gd_u32)__builtin_fmaf(gd_min(gd_max(c, 0.0f), 1.0f), 255.0f, 0.5f); }
-#else
-GD gd_u32 gd_unorm8(float c) { return (gd_u32)(gd_min(gd_max(c, 0.0f), 1.0f) * 255.0f + 0.5f); }
-#endif
 GD gd_u32 gd_pack_rgba8(float r, float g, float b, float a)
 {
     return gd_unorm8(r) | (gd_unorm8(g) << 8) | (gd_unorm8(b) << 16) | (gd_unorm8(a) << 24);

@@ -91,7 +91,9 @@ int compile_hip(const std::string& src, const char* name, std::vector<char>& cod
     hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), name, 1, hdr_src, hdr_name);
     if (r != HIPRTC_SUCCESS) return set_error(GAME_E_HIP, std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r));
     // One rounding per source operator: contraction off; fma only where the source says fma.
-    std::vector<std::string> flags = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+    // No SLP vectorisation: packed FP32 (v_pk_*_f32) issues at half rate on gfx950, so pairing two
+    // scalar operations into one packed instruction only adds the moves that build the pairs.
+    std::vector<std::string> flags = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
     // Tuning hook: extra hiprtc options, space separated (later options override earlier ones).
     if (const char* extra = getenv("GAME_HIP_FLAGS")) {
         std::string e(extra);
@@ -177,6 +179,8 @@ int upload_rows(game_hip_ctx* c, const float* uniforms, uint32_t nframes)
 int launch_frames(game_hip_ctx* c, uint32_t frame0, uint32_t count, uint32_t slot0, const uint32_t* prev, uint32_t row0,
                   uint32_t rows)
 {
+    // the kernel wraps slot0 + frame index with one conditional subtract
+    if (count == 0 || count > c->ring || slot0 >= c->ring) return set_error(GAME_E_ARGUMENT, "launch_frames: frame batch does not fit the ring");
     FrameParams P;
     P.out = c->frames;
     P.prev = prev;

@@ -81,13 +81,13 @@ static float noise2(float px, float py)   /* glsl.rs:141-150 */
 {
     float ix = gm_floor(px), iy = gm_floor(py);
     float fx = gm_fract(px), fy = gm_fract(py);
-    float ux = fx * fx * (3.0f - 2.0f * fx);
-    float uy = fy * fy * (3.0f - 2.0f * fy);
+    float ux = fx * fx * fmaf(-2.0f, fx, 3.0f);
+    float uy = fy * fy * fmaf(-2.0f, fy, 3.0f);
     float a = hash2(ix, iy);
     float b = hash2(ix + 1.0f, iy + 0.0f);
     float c = hash2(ix + 0.0f, iy + 1.0f);
     float d = hash2(ix + 1.0f, iy + 1.0f);
-    return gm_mix(gm_mix(a, b, ux), gm_mix(c, d, ux), uy) * 2.0f - 1.0f;
+    return fmaf(gm_mix(gm_mix(a, b, ux), gm_mix(c, d, ux), uy), 2.0f, -1.0f);
 }
 
 static int to_int_octaves(float o)   /* int(x): truncation; out-of-range values are clamped to [0, 32] */
@@ -102,12 +102,12 @@ static float fbm2(float px, float py, int octaves, float persistence, float lacu
     float value = 0.0f, amplitude = 1.0f, frequency = 1.0f, max_val = 0.0f;
     float qx = px, qy = py;
     for (int i = 0; i < octaves; i++) {
-        value = value + noise2(qx * frequency, qy * frequency) * amplitude;
+        value = fmaf(noise2(qx * frequency, qy * frequency), amplitude, value);
         max_val = max_val + amplitude;
         amplitude = amplitude * persistence;
         frequency = frequency * lacunarity;
-        float nx = qx * 0.8f - qy * 0.6f;
-        float ny = qx * 0.6f + qy * 0.8f;
+        float nx = fmaf(qx, 0.8f, -(qy * 0.6f));
+        float ny = fmaf(qx, 0.6f, qy * 0.8f);
         qx = nx; qy = ny;
     }
     return value / max_val;
@@ -172,7 +172,7 @@ static float voronoi2d(float px, float py, float scale)   /* glsl.rs:202-219 */
 static float apply_glow(float d, float intensity)   /* glsl.rs:102-107 */
 {
     float core = gm_smoothstep(0.005f, -0.005f, d);
-    float halo = intensity / (1.0f + gm_max(d, 0.0f) * gm_max(d, 0.0f) * intensity * intensity * 16.0f);
+    float halo = intensity / fmaf(gm_max(d, 0.0f) * gm_max(d, 0.0f) * intensity * intensity, 16.0f, 1.0f);
     return core + halo;
 }
 
@@ -205,7 +205,7 @@ static inline float arg_value(const ir_arg* a, const frame_consts* fc)
 static inline uint32_t pack_unorm8(float c)   /* framebuffer write: round(clamp(c, 0, 1) * 255) */
 {
     float t = gm_min(gm_max(c, 0.0f), 1.0f);
-    return (uint32_t)(t * 255.0f + 0.5f);
+    return (uint32_t)fmaf(t, 255.0f, 0.5f);
 }
 
 /* uvx, uvy: `uv` of glsl.rs:54. prev: previous frame's RGBA8 texel at this pixel. out: RGBA floats. */

@@ -51,13 +51,15 @@ static inline float gm_fract(float x)
 }
 static inline float gm_mod(float x, float y) { return x - y * floorf(x / y); }
 static inline float gm_step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
-static inline float gm_mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+/* Contraction points: GLSL leaves a*b+c contraction to the implementation; the render path fixes
+ * them, so each place below that says fmaf is one fused rounding on every machine. */
+static inline float gm_mix(float a, float b, float t) { return fmaf(b, t, a * (1.0f - t)); }
 static inline float gm_smoothstep(float e0, float e1, float x)
 {
     float t = gm_clamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
-    return t * t * (3.0f - 2.0f * t);
+    return t * t * fmaf(-2.0f, t, 3.0f);
 }
-static inline float gm_length2(float x, float y) { return sqrtf(x * x + y * y); }
+static inline float gm_length2(float x, float y) { return sqrtf(fmaf(x, x, y * y)); }
 
 /* ── sin / cos ────────────────────────────────────────────────────────────────────────────
  * k = rint(x * 2/pi); r = x - k*pi/2 by three-constant Cody-Waite with fma for |x| <= 32768,

@@ -1,7 +1,9 @@
 """Independent numpy (float32, one rounding per operation) restatement of the parts of the emitted
 GLSL that use no transcendental function, written from game-compiler/src/codegen/glsl.rs without
 looking at the C oracle's structure. Used to cross-check oracle/game_oracle.c bit for bit; numpy
-float32 arithmetic is IEEE single precision with no fused operations.
+float32 arithmetic is IEEE single precision with no fused operations; the places where the render
+path fixes a fused multiply-add (GLSL leaves contraction to the implementation) go through fma()
+below, which rounds once by way of float64 and round-to-odd.
 """
 import numpy as np
 
@@ -12,13 +14,29 @@ def f(x):
     return np.asarray(x, dtype=np.float32)
 
 
+def fma(a, b, c):
+    """Correctly rounded float32 a*b+c: the product is exact in float64, the sum is rounded to odd
+    (53 >= 2*24+2 bits), and the final float64 -> float32 conversion rounds once."""
+    a, b, c = (np.asarray(v, dtype=np.float32).astype(np.float64) for v in (a, b, c))
+    a, b, c = np.broadcast_arrays(a, b, c)
+    p = a * b
+    s = p + c
+    bb = s - p
+    e = (p - (s - bb)) + (c - bb)
+    bits = s.copy().view(np.int64)
+    need = np.isfinite(s) & np.isfinite(e) & (e != 0) & ((bits & 1) == 0)
+    same = (e > 0) == (s > 0)
+    bits = np.where(need, np.where(same, bits + 1, bits - 1), bits)
+    return bits.view(np.float64).astype(np.float32)
+
+
 def fract(x):
     r = x - np.floor(x)
     return np.where(r < F(1.0), r, F(np.nextafter(np.float32(1.0), np.float32(0.0)))).astype(np.float32)
 
 
 def mix(a, b, t):
-    return a * (F(1.0) - t) + b * t
+    return fma(b, t, a * (F(1.0) - t))
 
 
 def clamp(x, lo, hi):
@@ -27,7 +45,7 @@ def clamp(x, lo, hi):
 
 def smoothstep(e0, e1, x):
     t = clamp((x - F(e0)) / (F(e1) - F(e0)), 0.0, 1.0)
-    return t * t * (F(3.0) - F(2.0) * t)
+    return t * t * fma(F(-2.0), t, F(3.0))
 
 
 def hash2(px, py):  # glsl.rs:134-138
@@ -42,13 +60,13 @@ def hash2(px, py):  # glsl.rs:134-138
 def noise2(px, py):  # glsl.rs:141-150
     ix, iy = np.floor(px), np.floor(py)
     fx, fy = fract(px), fract(py)
-    ux = fx * fx * (F(3.0) - F(2.0) * fx)
-    uy = fy * fy * (F(3.0) - F(2.0) * fy)
+    ux = fx * fx * fma(F(-2.0), fx, F(3.0))
+    uy = fy * fy * fma(F(-2.0), fy, F(3.0))
     a = hash2(ix, iy)
     b = hash2(ix + F(1.0), iy + F(0.0))
     c = hash2(ix + F(0.0), iy + F(1.0))
     d = hash2(ix + F(1.0), iy + F(1.0))
-    return mix(mix(a, b, ux), mix(c, d, ux), uy) * F(2.0) - F(1.0)
+    return fma(mix(mix(a, b, ux), mix(c, d, ux), uy), F(2.0), F(-1.0))
 
 
 def fbm2(px, py, octaves, persistence, lacunarity):  # glsl.rs:155-169
@@ -56,11 +74,11 @@ def fbm2(px, py, octaves, persistence, lacunarity):  # glsl.rs:155-169
     amplitude, frequency, max_val = F(1.0), F(1.0), F(0.0)
     qx, qy = px, py
     for _ in range(octaves):
-        value = value + noise2(qx * frequency, qy * frequency) * amplitude
+        value = fma(noise2(qx * frequency, qy * frequency), amplitude, value)
         max_val = F(max_val + amplitude)
         amplitude = F(amplitude * F(persistence))
         frequency = F(frequency * F(lacunarity))
-        qx, qy = qx * F(0.8) - qy * F(0.6), qx * F(0.6) + qy * F(0.8)
+        qx, qy = fma(qx, F(0.8), -(qy * F(0.6))), fma(qx, F(0.6), qy * F(0.8))
     return value / max_val
 
 
@@ -68,7 +86,7 @@ def apply_glow(d, intensity):  # glsl.rs:102-107
     i = F(intensity)
     core = smoothstep(0.005, -0.005, d)
     md = np.maximum(d, F(0.0))
-    halo = i / (F(1.0) + md * md * i * i * F(16.0))
+    halo = i / fma(md * md * i * i, F(16.0), F(1.0))
     return core + halo
 
 
@@ -86,7 +104,7 @@ def pack(r, g, b, a):
     def u8(c):
         c = np.where(np.isnan(c), F(0.0), c)
         t = np.minimum(np.maximum(c, F(0.0)), F(1.0))
-        return (t * F(255.0) + F(0.5)).astype(np.uint32).astype(np.uint8)
+        return fma(t, F(255.0), F(0.5)).astype(np.uint32).astype(np.uint8)
     return np.stack([u8(r), u8(g), u8(b), u8(np.broadcast_to(f(a), r.shape))], axis=-1)
 
 
@@ -95,7 +113,7 @@ def render_c1(w, h):
     uvx, uvy = pixel_grid(w, h)
     aspect = F(w) / F(h)
     px, py = uvx * aspect, uvy
-    sdf = np.sqrt(px * px + py * py) - F(0.3)
+    sdf = np.sqrt(fma(px, px, py * py)) - F(0.3)
     g = apply_glow(sdf, 2.0)
     return pack(g * F(0.831), g * F(0.686), g * F(0.216), 1.0)
 
@@ -123,7 +141,7 @@ def render_c3_no_grain(w, h, bass, mid, treble):
     lum = r * F(0.299) + g * F(0.587) + b * F(0.114)
     add = np.maximum(lum - F(0.4), F(0.0)) * F(2.0)
     r, g, b = r + add, g + add, b + add
-    ln = np.sqrt(uvx * uvx + uvy * uvy)
+    ln = np.sqrt(fma(uvx, uvx, uvy * uvy))
     dirx = uvx / ln * F(0.6)
     r, b = r * (F(1.0) + dirx), b * (F(1.0) - dirx)
     fac = F(1.0) - smoothstep(0.8, F(0.8) + F(0.35), ln)

@@ -7,7 +7,7 @@ rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
 i=0
-for pass in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_WAVES" "GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_IFETCH"; do
+for pass in "${PMC_PASS1:-SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_WAVES}" "GRBM_GUI_ACTIVE" "${PMC_PASS3:-SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_IFETCH}"; do
   i=$((i+1))
   timeout -s KILL 240 rocprofv3 --pmc $pass -d $out/p$i -o pmc -- python3 $root/tools/ab_flags.py "$@" > $out/p${i}_stdout.txt 2>&1 || { echo "pass $i failed"; tail -5 $out/p${i}_stdout.txt; }
 done
