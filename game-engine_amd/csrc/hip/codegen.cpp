@@ -128,12 +128,13 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
          "    float inv_w, inv_h;\n"
          "};\n\n";
     k += "extern \"C\" __global__ __launch_bounds__(256) void game_frame(GameFrameParams P)\n{\n";
-    // wave64 tile = 8x8 pixels; a 256-thread workgroup covers 32x8 (4 waves side by side)
-    k += "#ifdef GD_PAD\n    for (int pad = 0; pad < GD_PAD; ++pad) asm volatile(\"s_nop 0\");\n#endif\n";
-    k += "    const gd_u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;\n";
-    k += "    const gd_u32 x0 = (blockIdx.x * 32u + wave * 8u + (lane & 7u)) * " + std::to_string(shape.pixels_per_lane) + "u;\n";
-    k += "    const gd_u32 ty = P.row0 + blockIdx.y * 8u + (lane >> 3);\n";
-    k += "    if (ty >= P.row0 + P.rows) return;\n";
+    // A lane owns pixels_per_lane consecutive pixels of one row, a wave 64 * pixels_per_lane of them,
+    // a 256-thread workgroup four such strips side by side: every store instruction of a wave writes
+    // one contiguous run of the row (256 B, or 1 KiB as 16-byte stores when pixels_per_lane is 4).
+    const std::string ppl = std::to_string(shape.pixels_per_lane);
+    k += "    const gd_u32 x0 = (blockIdx.x * 256u + threadIdx.x) * " + ppl + "u;\n";
+    k += "    const gd_u32 ty = P.row0 + blockIdx.y;\n";
+    k += "    if (x0 >= P.w) return;\n";
     k += "    const gd_u32 fidx = blockIdx.z;\n";
     k += "    const float* __restrict__ U = P.utab + (unsigned long long)(P.frame0 + fidx) * P.ustride;\n";
     // slot0 < ring and fidx < ring (checked by the host), so one conditional subtract wraps the ring
@@ -146,15 +147,23 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     k += "    s.bass = U[1]; s.mid = U[2]; s.treble = U[3];\n";
     k += "    const float vy = ((float)(P.h - 1u - ty) + 0.5f) * P.inv_h;\n";   // GL row 0 is the bottom row
     k += "    s.uvy = vy * 2.0f - 1.0f;\n";
-    if (shape.pixels_per_lane > 1) k += "#pragma unroll 1\n    for (gd_u32 kx = 0; kx < " + std::to_string(shape.pixels_per_lane) + "u; ++kx) {\n    const gd_u32 x = x0 + kx;\n";
-    else k += "    {\n    const gd_u32 x = x0;\n";
-    k += "    if (x < P.w) {\n";
+    if (shape.pixels_per_lane == 4) {
+        // the host picks this shape only when the width is a multiple of 4: rows stay 16-byte aligned
+        if (ir.uses_memory)
+            k += "    gd_u32x4 pv = {0u, 0u, 0u, 0u};\n"
+                 "    if (P.prev) pv = *(const gd_u32x4*)(P.prev + (unsigned long long)ty * P.w + x0);\n";
+        k += "    gd_u32x4 q;\n";
+        k += "#pragma unroll\n    for (gd_u32 kx = 0; kx < 4u; ++kx) {\n    const gd_u32 x = x0 + kx;\n";
+        k += "    {\n";
+        if (ir.uses_memory) k += "    const gd_u32 prev = pv[kx];\n";
+    } else {
+        k += "    {\n    const gd_u32 x = x0;\n    {\n";
+        if (ir.uses_memory)
+            k += "    const gd_u32 prev = P.prev ? P.prev[(unsigned long long)ty * P.w + x] : 0u;\n";
+    }
     k += "    const float vx = ((float)x + 0.5f) * P.inv_w;\n";
     k += "    s.uvx = vx * 2.0f - 1.0f;\n";
-    if (ir.uses_memory)
-        k += "    const gd_u32 prev = P.prev ? P.prev[(unsigned long long)ty * P.w + x] : 0u;\n";
-    if (ir.multi_layer) k += "    float fr = 0.0f, fg = 0.0f, fb = 0.0f, fa = 1.0f;\n";
-    else k += "    float fr = 0.0f, fg = 0.0f, fb = 0.0f, fa = 1.0f;\n";
+    k += "    float fr = 0.0f, fg = 0.0f, fb = 0.0f, fa = 1.0f;\n";
     for (size_t li = 0; li < ir.layers.size(); ++li) {
         const IrLayer& L = ir.layers[li];
         if (!L.is_pipeline || L.end_state != State::Color) continue;
@@ -170,8 +179,14 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
         }
         k += "    }\n";
     }
-    k += "    dst[x] = gd_pack_rgba8(fr, fg, fb, fa);\n";
-    k += "    }\n    }\n";
+    if (shape.pixels_per_lane == 4) {
+        k += "    q[kx] = gd_pack_rgba8(fr, fg, fb, fa);\n";
+        k += "    }\n    }\n";
+        k += "    *(gd_u32x4*)(dst + x0) = q;\n";
+    } else {
+        k += "    dst[x] = gd_pack_rgba8(fr, fg, fb, fa);\n";
+        k += "    }\n    }\n";
+    }
     k += "}\n";
     return k;
 }

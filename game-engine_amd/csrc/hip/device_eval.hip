@@ -11,7 +11,7 @@ using namespace game;
 namespace {
 
 enum EvalOp { EV_FRACT = 0, EV_SIN, EV_COS, EV_ATAN2, EV_HASH2, EV_NOISE2, EV_SIMPLEX, EV_VORONOI, EV_EXP2, EV_LOG2, EV_POW,
-              EV_MAX, EV_MIN, EV_FBM6, EV_SQRT, EV_DIV, EV_SMOOTHSTEP_GLOW, EV_MOD, EV_COUNT };
+              EV_MAX, EV_MIN, EV_FBM6, EV_SQRT, EV_DIV, EV_SMOOTHSTEP_GLOW, EV_MOD, EV_UNORM8, EV_COUNT };
 
 __global__ void eval_kernel(int op, uint32_t n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out)
 {
@@ -37,6 +37,7 @@ __global__ void eval_kernel(int op, uint32_t n, const float* __restrict__ a, con
     case EV_DIV: r = x / y; break;
     case EV_SMOOTHSTEP_GLOW: r = gd_smoothstep(0.005f, -0.005f, x); break;
     case EV_MOD: r = gd_mod(x, y); break;
+    case EV_UNORM8: r = gd_unorm8_to_float((gd_u32)x); break;
     default: break;
     }
     out[i] = r;

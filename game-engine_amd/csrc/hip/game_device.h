@@ -13,6 +13,7 @@
 #define GD static __device__ __forceinline__
 
 typedef unsigned int gd_u32;
+typedef gd_u32 gd_u32x4 __attribute__((ext_vector_type(4)));
 
 // ── scalar helpers ──────────────────────────────────────────────────────────────────────
 GD gd_u32 gd_bits(float f) { return __builtin_bit_cast(gd_u32, f); }
@@ -25,12 +26,16 @@ GD float gd_clamp(float x, float lo, float hi) { return gd_min(gd_max(x, lo), hi
 GD float gd_sqrt(float x) { return __builtin_sqrtf(x); }             // correctly rounded (hipcc/hiprtc default)
 // v_fract_f32: x - floor(x) clamped to the largest float below 1; NaN for NaN and infinities.
 GD float gd_fract(float x) { return __builtin_amdgcn_fractf(x); }
-GD float gd_mod(float x, float y) { return x - y * gd_floor(x / y); }
+// Quotients whose divisor is a stage argument or a constant of the emitted GLSL are one correctly
+// rounded reciprocal and one multiply (GLSL ES allows 2.5 ulp on a/b; this is within 1.5): with a
+// literal divisor the reciprocal folds at kernel-compile time and the quotient costs one v_mul_f32.
+GD float gd_rcp(float y) { return 1.0f / y; }
+GD float gd_mod(float x, float y) { return x - y * gd_floor(x * gd_rcp(y)); }
 GD float gd_step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
 GD float gd_mix(float a, float b, float t) { return __builtin_fmaf(b, t, a * (1.0f - t)); }
 GD float gd_smoothstep(float e0, float e1, float x)
 {
-    float t = gd_clamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    float t = gd_clamp((x - e0) * gd_rcp(e1 - e0), 0.0f, 1.0f);
     return t * t * __builtin_fmaf(-2.0f, t, 3.0f);
 }
 GD float gd_length2(float x, float y) { return gd_sqrt(__builtin_fmaf(x, x, y * y)); }
@@ -193,7 +198,7 @@ GD float gd_fbm2(float px, float py, int octaves, float persistence, float lacun
         float ny = __builtin_fmaf(qx, 0.6f, qy * 0.8f);
         qx = nx; qy = ny;
     }
-    return value / max_val;
+    return value * gd_rcp(max_val);
 }
 
 GD float gd_permute(float x) { return gd_mod((x * 34.0f + 1.0f) * x, 289.0f); }   // glsl.rs:173-175
@@ -326,7 +331,7 @@ GD void gb_rotate(GdPix& s, float angle)                                        
     s.px = nx; s.py = ny;
 }
 GD void gb_translate(GdPix& s, float x, float y) { s.px = s.px - x; s.py = s.py - y; }                  // :335-339
-GD void gb_scale(GdPix& s, float k) { s.px = s.px / k; s.py = s.py / k; }                               // :340-343
+GD void gb_scale(GdPix& s, float k) { float r = gd_rcp(k); s.px = s.px * r; s.py = s.py * r; }                               // :340-343
 GD void gb_twist(GdPix& s, float amount)                                                                // :344-349
 {
     float ts, tc;
@@ -468,12 +473,23 @@ GD void gb_spectrum(GdPix& s, float bass, float mid, float treble)              
     s.a = 1.0f;
 }
 
+// b / 255 for b in 0..255, correctly rounded, without the division sequence: q = b * RN(1/255) is
+// within one ulp, the residual b - 255 q is exact in one fma, and the corrected q is the correctly
+// rounded quotient for every one of the 256 inputs (checked exhaustively by the tests).
+GD float gd_unorm8_to_float(gd_u32 b)
+{
+    const float r = 0x1.010102p-8f;
+    float u = (float)b;
+    float q = u * r;
+    float e = __builtin_fmaf(-q, 255.0f, u);
+    return __builtin_fmaf(e, r, q);
+}
 // Memory feedback (game-compiler/src/codegen/memory.rs:38-45): mix with the previous frame's
 // RGBA8 texel at the same pixel.
 GD void gb_memory_mix(GdPix& s, gd_u32 prev, float decay)
 {
-    float pr = (float)(prev & 0xffu) / 255.0f, pg = (float)((prev >> 8) & 0xffu) / 255.0f;
-    float pb = (float)((prev >> 16) & 0xffu) / 255.0f, pa = (float)(prev >> 24) / 255.0f;
+    float pr = gd_unorm8_to_float(prev & 0xffu), pg = gd_unorm8_to_float((prev >> 8) & 0xffu);
+    float pb = gd_unorm8_to_float((prev >> 16) & 0xffu), pa = gd_unorm8_to_float(prev >> 24);
     s.r = gd_mix(s.r, pr, decay); s.g = gd_mix(s.g, pg, decay);
     s.b = gd_mix(s.b, pb, decay); s.a = gd_mix(s.a, pa, decay);
 }

@@ -124,10 +124,25 @@ int compile_hip(const std::string& src, const char* name, std::vector<char>& cod
     return GAME_OK;
 }
 
-KernelShape shape_for(const Ir& ir)
+// Pixels per lane. Cinematics whose stages are a few dozen instructions per pixel are bound by the
+// frame store (and the previous-frame load): four pixels per lane turn those into 16-byte accesses.
+// Noise-heavy cinematics are bound by VALU issue and keep one pixel per lane (fewest registers,
+// no unrolled copies of a long body). Rows stay 16-byte aligned only when the width is a multiple of 4.
+KernelShape shape_for(const Ir& ir, uint32_t width)
 {
     KernelShape s;
-    s.pixels_per_lane = 1;
+    bool heavy = false;
+    for (const IrStage& st : ir.stages)
+        switch (st.builtin) {
+        case B_FBM: case B_SIMPLEX: case B_VORONOI: case B_DOMAIN_WARP: case B_CURL_NOISE: case B_CONCENTRIC_WAVES: case B_DISPLACE:
+            heavy = true; break;
+        default: break;
+        }
+    s.pixels_per_lane = (!heavy && width % 4u == 0u) ? 4u : 1u;
+    if (const char* e = getenv("GAME_HIP_PPL")) {   // tuning hook
+        int v = atoi(e);
+        if (v == 1 || (v == 4 && width % 4u == 0u)) s.pixels_per_lane = (uint32_t)v;
+    }
     uint32_t row = BU_COUNT + (uint32_t)ir.uniforms.size();
     s.time_slot = row;
     s.aspect_slot = row + 1;
@@ -191,8 +206,8 @@ int launch_frames(game_hip_ctx* c, uint32_t frame0, uint32_t count, uint32_t slo
     P.inv_w = 1.0f / (float)c->w;
     P.inv_h = 1.0f / (float)c->h;
     void* args[] = {&P};
-    uint32_t gx = (c->w + 32u * c->shape.pixels_per_lane - 1u) / (32u * c->shape.pixels_per_lane);
-    uint32_t gy = (rows + 7u) / 8u;
+    uint32_t gx = (c->w + 256u * c->shape.pixels_per_lane - 1u) / (256u * c->shape.pixels_per_lane);
+    uint32_t gy = rows;   // one row per workgroup row; rows <= height <= 65535 is checked at creation
     // Tuning hook: dynamic LDS request per workgroup, to cap resident workgroups per CU.
     static const unsigned lds_bytes = getenv("GAME_HIP_LDS_BYTES") ? (unsigned)atoi(getenv("GAME_HIP_LDS_BYTES")) : 0u;
     HIP_TRY(hipModuleLaunchKernel(c->fn, gx, gy, count, 256, 1, 1, lds_bytes, c->stream, args, nullptr));
@@ -267,7 +282,7 @@ int game_hip_compile_only(const game_ir* ir, size_t* code_bytes)
 {
     if (!ir) return set_error(GAME_E_ARGUMENT, "game_hip_compile_only: null ir");
     std::vector<char> code;
-    std::string src = generate_frame_kernel(*ir->ir, shape_for(*ir->ir));
+    std::string src = generate_frame_kernel(*ir->ir, shape_for(*ir->ir, 3840u));
     int rc = compile_hip(src, "game_frame.hip", code);
     if (rc) return rc;
     size_t total = code.size();
@@ -291,7 +306,7 @@ int game_hip_dump_code(const game_ir* ir, const char* path_prefix)
         return ok;
     };
     std::vector<char> code;
-    std::string src = generate_frame_kernel(*ir->ir, shape_for(*ir->ir));
+    std::string src = generate_frame_kernel(*ir->ir, shape_for(*ir->ir, 3840u));
     int rc = compile_hip(src, "game_frame.hip", code);
     if (rc) return rc;
     std::string pre(path_prefix);
@@ -311,8 +326,8 @@ int game_hip_create(const game_ir* ir, uint32_t width, uint32_t height, int devi
 {
     if (!ir || !out) return set_error(GAME_E_ARGUMENT, "game_hip_create: null argument");
     *out = nullptr;
-    if (width == 0 || height == 0 || width > 65536 || height > 65536)
-        return set_error(GAME_E_ARGUMENT, "game_hip_create: width/height must be in 1..65536");
+    if (width == 0 || height == 0 || width > 65536 || height > 65535)
+        return set_error(GAME_E_ARGUMENT, "game_hip_create: width must be in 1..65536 and height in 1..65535");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
@@ -324,7 +339,7 @@ int game_hip_create(const game_ir* ir, uint32_t width, uint32_t height, int devi
     c->ir = *ir->ir;
     c->device = device;
     c->w = width; c->h = height;
-    c->shape = shape_for(c->ir);
+    c->shape = shape_for(c->ir, c->w);
     c->row_floats = BU_COUNT + (uint32_t)c->ir.uniforms.size();
     c->ustride = c->row_floats + 2;
     c->source = generate_frame_kernel(c->ir, c->shape);

@@ -110,7 +110,7 @@ static float fbm2(float px, float py, int octaves, float persistence, float lacu
         float ny = fmaf(qx, 0.6f, qy * 0.8f);
         qx = nx; qy = ny;
     }
-    return value / max_val;
+    return value * gm_rcp(max_val);
 }
 
 static float permute1(float x) { return gm_mod((x * 34.0f + 1.0f) * x, 289.0f); }   /* glsl.rs:173-175 */
@@ -274,7 +274,7 @@ static void shade_pixel(const ir_view* ir, const frame_consts* fc, float uvx, fl
                 break;
             }
             case B_TRANSLATE: px = px - a0; py = py - a1; break;                                   /* :335-339 */
-            case B_SCALE: px = px / a0; py = py / a0; break;                                       /* :340-343 */
+            case B_SCALE: { float r = gm_rcp(a0); px = px * r; py = py * r; } break;                                       /* :340-343 */
             case B_TWIST: {                                                                        /* :344-349 */
                 float tw = py * a0;
                 float c = gm_cos(tw), s = gm_sin(tw);

@@ -49,14 +49,16 @@ static inline float gm_fract(float x)
     if (f != f) return f;
     return f < 1.0f ? f : 0x1.fffffep-1f;
 }
-static inline float gm_mod(float x, float y) { return x - y * floorf(x / y); }
+/* Quotients by a stage argument or a GLSL constant: one correctly rounded reciprocal, one multiply. */
+static inline float gm_rcp(float y) { return 1.0f / y; }
+static inline float gm_mod(float x, float y) { return x - y * floorf(x * gm_rcp(y)); }
 static inline float gm_step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
 /* Contraction points: GLSL leaves a*b+c contraction to the implementation; the render path fixes
  * them, so each place below that says fmaf is one fused rounding on every machine. */
 static inline float gm_mix(float a, float b, float t) { return fmaf(b, t, a * (1.0f - t)); }
 static inline float gm_smoothstep(float e0, float e1, float x)
 {
-    float t = gm_clamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    float t = gm_clamp((x - e0) * gm_rcp(e1 - e0), 0.0f, 1.0f);
     return t * t * fmaf(-2.0f, t, 3.0f);
 }
 static inline float gm_length2(float x, float y) { return sqrtf(fmaf(x, x, y * y)); }

@@ -44,7 +44,7 @@ def clamp(x, lo, hi):
 
 
 def smoothstep(e0, e1, x):
-    t = clamp((x - F(e0)) / (F(e1) - F(e0)), 0.0, 1.0)
+    t = clamp((x - F(e0)) * (F(1.0) / (F(e1) - F(e0))), 0.0, 1.0)   # one reciprocal, one multiply
     return t * t * fma(F(-2.0), t, F(3.0))
 
 
@@ -79,7 +79,7 @@ def fbm2(px, py, octaves, persistence, lacunarity):  # glsl.rs:155-169
         amplitude = F(amplitude * F(persistence))
         frequency = F(frequency * F(lacunarity))
         qx, qy = fma(qx, F(0.8), -(qy * F(0.6))), fma(qx, F(0.6), qy * F(0.8))
-    return value / max_val
+    return value * (F(1.0) / max_val)
 
 
 def apply_glow(d, intensity):  # glsl.rs:102-107

@@ -94,6 +94,23 @@ def test_device_division_and_sqrt_are_correctly_rounded(game):
     assert np.array_equal(_bits(game.device_eval("div", tiny, b[:1000])), _bits(tiny / b[:1000]))
 
 
+def test_unorm8_to_float_equals_division_for_all_bytes(game):
+    b = np.arange(256, dtype=np.float32)
+    assert np.array_equal(_bits(game.device_eval("unorm8", b)), _bits(b / np.float32(255.0)))
+
+
+def test_reciprocal_multiply_quotients(game):
+    # mod and smoothstep are defined with one correctly rounded reciprocal and one multiply
+    rng = np.random.default_rng(9)
+    x = ((rng.random(50000, dtype=np.float32) * 2 - 1) * np.float32(1e4)).astype(np.float32)
+    y = np.full_like(x, 289.0)
+    want = x - y * np.floor(x * (np.float32(1.0) / y))
+    assert np.array_equal(_bits(game.device_eval("mod", x, y)), _bits(want))
+    d = ((rng.random(50000, dtype=np.float32) * 2 - 1) * np.float32(0.02)).astype(np.float32)
+    from np_restatement import smoothstep
+    assert np.array_equal(_bits(game.device_eval("smoothstep_glow", d)), _bits(smoothstep(0.005, -0.005, d)))
+
+
 # ── the five benchmark cinematics at oracle-sized frames ────────────────────────────────
 def test_c1_hello(game, oracle):
     got = check(game, oracle, C1_HELLO, 256, 256, [0.0, 1.0 / 60, 2.5])

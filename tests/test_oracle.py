@@ -260,3 +260,16 @@ def test_seed_particles_known_answer(oracle):
         z ^= z >> 31
         vals.append(np.float32(z >> 40) * np.float32(2.0 ** -23) - np.float32(1.0))
     assert np.array_equal(p[:, :2].reshape(-1), np.array(vals, dtype=np.float32)) and np.all(p[:, 2:] == 0)
+
+
+def test_unorm8_fma_sequence_equals_division_for_all_bytes():
+    """The render path converts a stored byte with q = b*r, e = fma(-q, 255, b), fma(e, r, q) where
+    r = RN(1/255); the oracle divides. Both must agree for every byte."""
+    from np_restatement import fma
+    b = np.arange(256, dtype=np.float32)
+    r = np.float32(1.0) / np.float32(255.0)
+    assert float(r).hex() == "0x1.0101020000000p-8"
+    q = b * r
+    e = fma(-q, np.float32(255.0), b)
+    got = fma(e, r, q)
+    assert np.array_equal(got.view(np.uint32), (b / np.float32(255.0)).view(np.uint32))

@@ -17,7 +17,11 @@ rows = cin.uniform_rows([k / 60 for k in range(batch)], w, h, audio={"bass": 0.8
 rs = []
 ref = None
 for v in variants:
-    os.environ["GAME_HIP_FLAGS"] = v
+    # a variant is hiprtc flags, optionally prefixed by "PPL=n;" (pixels per lane)
+    ppl, _, fl = v.partition(";") if v.startswith("PPL=") else ("", "", v)
+    os.environ["GAME_HIP_FLAGS"] = fl
+    os.environ.pop("GAME_HIP_PPL", None)
+    if ppl: os.environ["GAME_HIP_PPL"] = ppl[4:]
     r = cin.renderer(w, h); r.set_ring(max(2, batch))
     band = r.render_band(rows[:1], h // 2, 8)[0]
     if ref is None: ref = band
