@@ -27,6 +27,23 @@ import conftest as T  # noqa: E402  (fixtures for the benchmark cinematics + loa
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X vector FP32 peak: 256 CU x 4 SIMD x 32 lanes x 2 (fma) x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
+SIMDS, CLOCK_HZ = 1024, 2.4e9     # 256 CUs x 4 SIMDs; one wave64 VALU instruction per 2 cycles per SIMD at best
+
+
+def measured_counters(key, frames_per_launch):
+    """HBM traffic and VALU instruction counts per launch from the committed rocprofv3 PMC summary
+    (profiles/r*_traffic.json, written from the output of tools/profile_bench.sh). The counters are
+    collected in separate profiler runs of this same command, so they are read back here instead of
+    being measured inside the timed run; None when the profile does not cover this launch shape."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            rec = json.load(open(path)).get(key)
+        except (OSError, ValueError):
+            continue
+        if rec and rec.get("frames_per_launch") == frames_per_launch:
+            return rec
+    return None
 
 # Algorithmic work per pixel (flop convention: add/sub/mul/div/min/max/abs/floor/fract/compare/select
 # = 1, sin/cos/sqrt/atan = 1, mul+add pair = 2), summed over the stages of each cinematic.
@@ -160,18 +177,24 @@ def run_frames(args, torch, rank, world, local, key):
         if args.events and launches:
             px_launch = (nrows if banded else h) * w * (1 if banded else batch)
             sec = kernel_ms / launches / 1e3
+            pmc = measured_counters(key, 1 if banded else batch) if world == 1 else None
+            traffic = round(pmc["traffic_bytes_per_launch"]) if pmc else None
             if cfg["bound"] == "valu":
                 ach = px_launch * cfg["flops_px"] / sec / 1e12
                 out["roofline"] = {"bound": "valu", "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                                   "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
                                    "kernel": "game_frame", "avg_launch_ms": round(sec * 1e3, 4), "pixels_per_launch": px_launch,
                                    "flops_per_pixel": cfg["flops_px"]}
             else:
                 ach = px_launch * cfg["bytes_px"] / sec / 1e9
                 out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                                   "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
                                    "kernel": "game_frame", "avg_launch_ms": round(sec * 1e3, 4), "pixels_per_launch": px_launch,
                                    "bytes_per_pixel": cfg["bytes_px"]}
+            if pmc:
+                # share of the VALU issue slots (one wave64 instruction per 2 cycles per SIMD) this launch used
+                out["roofline"]["valu_issue_frac"] = round(pmc["waves_per_launch"] * pmc["valu_instructions_per_wave"] * 2.0 / (SIMDS * CLOCK_HZ * sec), 4)
+                out["roofline"]["valu_instructions_per_wave"] = round(pmc["valu_instructions_per_wave"], 1)
         if world == 1 and not args.no_cpu:
             oracle = T.Oracle()
             out["cpu_baseline"] = cpu_baseline_frames(game, oracle, cin, cfg, args.cpu_seconds)
