@@ -24,7 +24,8 @@ def frames_for_rank(nframes, rank, world):
 
 def band_for_rank(height, rank, world, align=8):
     """(row0, rows) of the horizontal band owned by `rank`; bands are multiples of `align` rows
-    (the 8-row wave tile) except the last one, and may be empty when height < world * align."""
+    except the last one (the kernel itself works row by row, so any split is valid), and may be
+    empty when height < world * align."""
     per = ((height + world - 1) // world + align - 1) // align * align
     row0 = min(height, rank * per)
     return row0, max(0, min(height, row0 + per) - row0)
