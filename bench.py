@@ -27,6 +27,7 @@ import conftest as T  # noqa: E402  (fixtures for the benchmark cinematics + loa
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X vector FP32 peak: 256 CU x 4 SIMD x 32 lanes x 2 (fma) x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
+REHEARSE = os.environ.get("GAME_BENCH_REHEARSE") == "1"   # not a measurement mode: see dist_setup
 SIMDS, CLOCK_HZ = 1024, 2.4e9     # 256 CUs x 4 SIMDs; one wave64 VALU instruction per 2 cycles per SIMD at best
 
 
@@ -66,10 +67,15 @@ def dist_setup(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if REHEARSE:
+        local = 0       # rehearsal of the N > 1 control flow on a one-GPU box: every rank shares GPU 0, gloo rendezvous
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if REHEARSE:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     if world != n_gpus:
         raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run --nproc-per-node N")
     return torch, rank, world, local
@@ -87,7 +93,7 @@ def max_over_ranks(torch, world, value):
     if world == 1:
         return value
     import torch.distributed as dist
-    t = torch.tensor([value], dtype=torch.float64, device="cuda")
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if REHEARSE else "cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -285,6 +291,8 @@ def main():
     torch.cuda.set_device(local)
     out = run_particles(args, torch, rank, world, local) if args.config == "c5" else run_frames(args, torch, rank, world, local, args.config)
     if rank == 0:
+        if REHEARSE:
+            out["data"] = "synthetic (REHEARSAL: all ranks on one GPU, not a measurement)"
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
