@@ -266,12 +266,20 @@ std::string generate_gravity_kernel(const Ir& ir)
     k += "#pragma unroll 4\n";
     k += "        for (gd_u32 t = 0; t < lim; ++t) {\n";
     k += "            const float dx = tx[t] - sx, dy = ty[t] - sy;\n";
-    k += "            const float dist = gd_max(gd_length2(dx, dy), 0.001f);\n";
-    k += "            const float dirx = dx / dist, diry = dy / dist;\n";
+    // dist = max(length(diff), 0.001); dir = diff * (1 / dist); force = fma(dir, law, force).
+    // Squared distances below 2^-100 (coincident particles, NaN) all give dist = 0.001, so they are
+    // raised to 2^-100 and every finite case runs the short exact sqrt / reciprocal sequences;
+    // an infinite squared distance keeps the IEEE results (dist = inf, 1 / dist = 0).
+    k += "            const float d2 = __builtin_fmaf(dx, dx, dy * dy);\n";
+    k += "            const bool finite = d2 < __builtin_inff() || d2 != d2;\n";
+    k += "            const float root = gd_sqrt_core(gd_max(d2, 0x1p-100f));\n";
+    k += "            const float dist = finite ? gd_max(root, 0.001f) : d2;\n";
+    k += "            const float inv = finite ? gd_rcp_core(gd_max(root, 0.001f)) : 0.0f;\n";
+    k += "            const float dirx = dx * inv, diry = dy * inv;\n";
     k += "            const float f = " + law_expr(ir) + ";\n";
     k += "            const bool self = (base + t) == idx;\n";
-    k += "            fx = self ? fx : fx + dirx * f;\n";
-    k += "            fy = self ? fy : fy + diry * f;\n";
+    k += "            fx = self ? fx : __builtin_fmaf(dirx, f, fx);\n";
+    k += "            fy = self ? fy : __builtin_fmaf(diry, f, fy);\n";
     k += "        }\n";
     k += "        __syncthreads();\n";
     k += "    }\n";

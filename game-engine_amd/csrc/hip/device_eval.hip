@@ -44,7 +44,7 @@ __global__ void eval_kernel(int op, uint32_t n, const float* __restrict__ a, con
 }
 
 // which: 0 = fract(x) for every bit pattern x; 1 = max(x, c), 2 = min(x, c) for every x and the
-// probe constants below.
+// probe constants below; 3 = gd_sqrt(x), 4 = gd_rcp(x) against the compiler's IEEE expansions.
 __global__ void exhaustive_kernel(int which, unsigned long long* mismatches, uint32_t* first_bad)
 {
     const float probes[6] = {0.0f, -0.0f, 1.0f, -1.0f, __builtin_inff(), __builtin_nanf("")};
@@ -56,6 +56,11 @@ __global__ void exhaustive_kernel(int which, unsigned long long* mismatches, uin
             float hw = gd_fract(x);
             float f = x - gd_floor(x);
             float want = (f != f) ? f : (f < 1.0f ? f : 0x1.fffffep-1f);
+            bool same = (hw != hw && want != want) || gd_bits(hw) == gd_bits(want);
+            if (!same) { ++bad; atomicMin(first_bad, (gd_u32)v); }
+        } else if (which == 3 || which == 4) {
+            float hw = which == 3 ? gd_sqrt(x) : gd_rcp(x);
+            float want = which == 3 ? __builtin_sqrtf(x) : 1.0f / x;
             bool same = (hw != hw && want != want) || gd_bits(hw) == gd_bits(want);
             if (!same) { ++bad; atomicMin(first_bad, (gd_u32)v); }
         } else {
@@ -103,7 +108,7 @@ int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out
 
 int game_hip_check_exhaustive(int which, uint64_t* mismatches, uint32_t* first_bad)
 {
-    if (which < 0 || which > 2 || !mismatches || !first_bad) return set_error(GAME_E_ARGUMENT, "game_hip_check_exhaustive: bad argument");
+    if (which < 0 || which > 4 || !mismatches || !first_bad) return set_error(GAME_E_ARGUMENT, "game_hip_check_exhaustive: bad argument");
     unsigned long long* dm = nullptr;
     uint32_t* df = nullptr;
     HIP_TRY(hipMalloc((void**)&dm, 8));

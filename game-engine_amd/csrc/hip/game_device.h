@@ -23,13 +23,42 @@ GD float gd_floor(float x) { return __builtin_floorf(x); }           // v_floor_
 GD float gd_max(float a, float b) { return __builtin_fmaxf(a, b); }  // v_max_f32: NaN -> other operand, -0 < +0
 GD float gd_min(float a, float b) { return __builtin_fminf(a, b); }  // v_min_f32
 GD float gd_clamp(float x, float lo, float hi) { return gd_min(gd_max(x, lo), hi); }
-GD float gd_sqrt(float x) { return __builtin_sqrtf(x); }             // correctly rounded (hipcc/hiprtc default)
+// Correctly rounded square root. For 2^-100 <= x < inf the five-instruction sequence below (v_rsq_f32,
+// g = x r, h = r / 2, one residual correction through two fmas) returns the IEEE result for every
+// input; game_hip_check_exhaustive(3) compares gd_sqrt with the IEEE expansion over all 2^32 bit
+// patterns. Everything else (zero, subnormal, negative, inf, NaN) takes the compiler's IEEE expansion.
+GD float gd_sqrt_core(float x)
+{
+    float r = __builtin_amdgcn_rsqf(x);
+    float g = x * r, h = 0.5f * r;
+    float d = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(d, h, g);
+}
+GD float gd_sqrt(float x)
+{
+    if (__builtin_constant_p(x)) return __builtin_sqrtf(x);
+    if (x >= 0x1p-100f && x < __builtin_inff()) return gd_sqrt_core(x);
+    return __builtin_sqrtf(x);
+}
 // v_fract_f32: x - floor(x) clamped to the largest float below 1; NaN for NaN and infinities.
 GD float gd_fract(float x) { return __builtin_amdgcn_fractf(x); }
 // Quotients whose divisor is a stage argument or a constant of the emitted GLSL are one correctly
 // rounded reciprocal and one multiply (GLSL ES allows 2.5 ulp on a/b; this is within 1.5): with a
 // literal divisor the reciprocal folds at kernel-compile time and the quotient costs one v_mul_f32.
-GD float gd_rcp(float y) { return 1.0f / y; }
+// Correctly rounded 1 / y: v_rcp_f32 and one Newton step give the IEEE result for every y with
+// 2^-126 <= |y| < 2^126 (game_hip_check_exhaustive(4), all 2^32 bit patterns); other inputs divide.
+GD float gd_rcp_core(float y)
+{
+    float r = __builtin_amdgcn_rcpf(y);
+    return __builtin_fmaf(__builtin_fmaf(-y, r, 1.0f), r, r);
+}
+GD float gd_rcp(float y)
+{
+    if (__builtin_constant_p(y)) return 1.0f / y;
+    float a = gd_abs(y);
+    if (a >= 0x1p-126f && a < 0x1p126f) return gd_rcp_core(y);
+    return 1.0f / y;
+}
 GD float gd_mod(float x, float y) { return x - y * gd_floor(x * gd_rcp(y)); }
 GD float gd_step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
 GD float gd_mix(float a, float b, float t) { return __builtin_fmaf(b, t, a * (1.0f - t)); }

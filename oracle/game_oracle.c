@@ -570,9 +570,10 @@ static void gravity_range(const grav_job* J)
             if (j == idx) continue;
             float dx = J->in[4 * j] - sx, dy = J->in[4 * j + 1] - sy;
             float dist = gm_max(gm_length2(dx, dy), 0.001f);
-            float dirx = dx / dist, diry = dy / dist;
+            float inv = gm_rcp(dist);                                           /* dir = diff / dist: one reciprocal */
+            float dirx = dx * inv, diry = dy * inv;
             float f = eval_law(ir->law, ir->h->n_law, dist, J->time);
-            fx = fx + dirx * f; fy = fy + diry * f;
+            fx = fmaf(dirx, f, fx); fy = fmaf(diry, f, fy);                     /* contraction point */
         }
         float vx = J->in[4 * idx + 2] * ir->h->damping + fx * J->dt;            /* gravity.rs:92-96 */
         float vy = J->in[4 * idx + 3] * ir->h->damping + fy * J->dt;
