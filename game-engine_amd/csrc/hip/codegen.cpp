@@ -240,6 +240,7 @@ std::string generate_gravity_kernel(const Ir& ir)
     std::string k;
     k += "// generated gravity step for cinematic \"" + ir.name + "\"\n";
     k += "#include \"game_device.h\"\n\n";
+    k += "#ifndef GD_GRAV_UNROLL\n#define GD_GRAV_UNROLL 8\n#endif\n";
     k += "GD float gd_ceil(float x) { return -gd_floor(-x); }\n";
     k += "GD float gd_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }\n\n";
     k += "struct GameGravityParams {\n"
@@ -257,30 +258,55 @@ std::string generate_gravity_kernel(const Ir& ir)
     k += "    const gd_u32 idx = P.first + (live ? local : 0u);\n";
     k += "    const float sx = P.xin[idx], sy = P.yin[idx];\n";
     k += "    float fx = 0.0f, fy = 0.0f;\n";
+    // Inner loop over one LDS tile, in three builds. dist = max(length(diff), 0.001) is computed as
+    // sqrt(max(d2, c)) with c = 0x1.0c6f7ap-20, the smallest float whose correctly rounded root is
+    // 0.001f (sqrt is monotonic, so both forms agree for every d2, NaN included); the short exact
+    // sqrt / reciprocal sequences apply because c <= max(d2, c) < inf whenever d2 is not +inf.
+    //   check_inf : some position of the tile or of this workgroup is NaN or beyond 2^60, so d2 may be
+    //               +inf: keep the IEEE results for that case (dist = inf, 1 / dist = 0)
+    //   check_self: the tile overlaps this workgroup's own particles (the j == idx term is skipped)
+    auto tile_loop = [&](bool check_self, bool check_inf) {
+        std::string b;
+        b += "#pragma unroll GD_GRAV_UNROLL\n";
+        b += "            for (gd_u32 t = 0; t < lim; ++t) {\n";
+        b += "                const float dx = tx[t] - sx, dy = ty[t] - sy;\n";
+        b += "                const float d2 = __builtin_fmaf(dx, dx, dy * dy);\n";
+        b += "                float root, rinv;\n";
+        b += "                gd_sqrt_rcp_core(gd_max(d2, 0x1.0c6f7ap-20f), root, rinv);\n";
+        if (check_inf) {
+            b += "                const bool finite = d2 < __builtin_inff() || d2 != d2;\n";
+            b += "                const float dist = finite ? root : d2;\n";
+            b += "                const float inv = finite ? rinv : 0.0f;\n";
+        } else {
+            b += "                const float dist = root;\n";
+            b += "                const float inv = rinv;\n";
+        }
+        b += "                const float dirx = dx * inv, diry = dy * inv;\n";
+        b += "                const float f = " + law_expr(ir) + ";\n";
+        if (check_self) {
+            b += "                const bool self = (base + t) == idx;\n";
+            b += "                fx = self ? fx : __builtin_fmaf(dirx, f, fx);\n";
+            b += "                fy = self ? fy : __builtin_fmaf(diry, f, fy);\n";
+        } else {
+            b += "                fx = __builtin_fmaf(dirx, f, fx);\n";
+            b += "                fy = __builtin_fmaf(diry, f, fy);\n";
+        }
+        b += "                (void)dist;\n";
+        b += "            }\n";
+        return b;
+    };
+    k += "    const gd_u32 wg_first = P.first + blockIdx.x * 256u;\n";
+    k += "    const bool own_wild = !(gd_abs(sx) <= 0x1p60f && gd_abs(sy) <= 0x1p60f);\n";
     k += "    for (gd_u32 base = 0; base < P.n; base += 256u) {\n";
     k += "        const gd_u32 j0 = base + threadIdx.x;\n";
-    k += "        tx[threadIdx.x] = j0 < P.n ? P.xin[j0] : 0.0f;\n";
-    k += "        ty[threadIdx.x] = j0 < P.n ? P.yin[j0] : 0.0f;\n";
-    k += "        __syncthreads();\n";
+    k += "        const float lx = j0 < P.n ? P.xin[j0] : 0.0f, ly = j0 < P.n ? P.yin[j0] : 0.0f;\n";
+    k += "        tx[threadIdx.x] = lx;\n";
+    k += "        ty[threadIdx.x] = ly;\n";
+    k += "        const int wild = __syncthreads_or((int)(own_wild || !(gd_abs(lx) <= 0x1p60f && gd_abs(ly) <= 0x1p60f)));\n";
     k += "        const gd_u32 lim = (P.n - base) < 256u ? (P.n - base) : 256u;\n";
-    k += "#pragma unroll 4\n";
-    k += "        for (gd_u32 t = 0; t < lim; ++t) {\n";
-    k += "            const float dx = tx[t] - sx, dy = ty[t] - sy;\n";
-    // dist = max(length(diff), 0.001); dir = diff * (1 / dist); force = fma(dir, law, force).
-    // Squared distances below 2^-100 (coincident particles, NaN) all give dist = 0.001, so they are
-    // raised to 2^-100 and every finite case runs the short exact sqrt / reciprocal sequences;
-    // an infinite squared distance keeps the IEEE results (dist = inf, 1 / dist = 0).
-    k += "            const float d2 = __builtin_fmaf(dx, dx, dy * dy);\n";
-    k += "            const bool finite = d2 < __builtin_inff() || d2 != d2;\n";
-    k += "            const float root = gd_sqrt_core(gd_max(d2, 0x1p-100f));\n";
-    k += "            const float dist = finite ? gd_max(root, 0.001f) : d2;\n";
-    k += "            const float inv = finite ? gd_rcp_core(gd_max(root, 0.001f)) : 0.0f;\n";
-    k += "            const float dirx = dx * inv, diry = dy * inv;\n";
-    k += "            const float f = " + law_expr(ir) + ";\n";
-    k += "            const bool self = (base + t) == idx;\n";
-    k += "            fx = self ? fx : __builtin_fmaf(dirx, f, fx);\n";
-    k += "            fy = self ? fy : __builtin_fmaf(diry, f, fy);\n";
-    k += "        }\n";
+    k += "        const bool overlaps = base < wg_first + 256u && wg_first < base + 256u;\n";
+    k += "        if (wild) {\n" + tile_loop(true, true) + "        } else if (overlaps) {\n" + tile_loop(true, false) +
+         "        } else {\n" + tile_loop(false, false) + "        }\n";
     k += "        __syncthreads();\n";
     k += "    }\n";
     k += "    if (!live) return;\n";

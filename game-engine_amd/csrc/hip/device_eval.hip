@@ -44,7 +44,8 @@ __global__ void eval_kernel(int op, uint32_t n, const float* __restrict__ a, con
 }
 
 // which: 0 = fract(x) for every bit pattern x; 1 = max(x, c), 2 = min(x, c) for every x and the
-// probe constants below; 3 = gd_sqrt(x), 4 = gd_rcp(x) against the compiler's IEEE expansions.
+// probe constants below; 3 = gd_sqrt(x), 4 = gd_rcp(x) against the compiler's IEEE expansions; 5 = gd_sqrt_rcp_core
+// against sqrtf(x) and 1 / sqrtf(x) for 2^-100 <= x < inf.
 __global__ void exhaustive_kernel(int which, unsigned long long* mismatches, uint32_t* first_bad)
 {
     const float probes[6] = {0.0f, -0.0f, 1.0f, -1.0f, __builtin_inff(), __builtin_nanf("")};
@@ -63,6 +64,12 @@ __global__ void exhaustive_kernel(int which, unsigned long long* mismatches, uin
             float want = which == 3 ? __builtin_sqrtf(x) : 1.0f / x;
             bool same = (hw != hw && want != want) || gd_bits(hw) == gd_bits(want);
             if (!same) { ++bad; atomicMin(first_bad, (gd_u32)v); }
+        } else if (which == 5) {
+            if (!(x >= 0x1p-100f && x < __builtin_inff())) continue;
+            float root, inv;
+            gd_sqrt_rcp_core(x, root, inv);
+            float want_root = __builtin_sqrtf(x), want_inv = 1.0f / want_root;
+            if (gd_bits(root) != gd_bits(want_root) || gd_bits(inv) != gd_bits(want_inv)) { ++bad; atomicMin(first_bad, (gd_u32)v); }
         } else {
             for (int p = 0; p < 6; ++p) {
                 float c = probes[p];
@@ -108,7 +115,7 @@ int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out
 
 int game_hip_check_exhaustive(int which, uint64_t* mismatches, uint32_t* first_bad)
 {
-    if (which < 0 || which > 4 || !mismatches || !first_bad) return set_error(GAME_E_ARGUMENT, "game_hip_check_exhaustive: bad argument");
+    if (which < 0 || which > 5 || !mismatches || !first_bad) return set_error(GAME_E_ARGUMENT, "game_hip_check_exhaustive: bad argument");
     unsigned long long* dm = nullptr;
     uint32_t* df = nullptr;
     HIP_TRY(hipMalloc((void**)&dm, 8));

@@ -34,6 +34,25 @@ GD float gd_sqrt_core(float x)
     float d = __builtin_fmaf(-g, g, x);
     return __builtin_fmaf(d, h, g);
 }
+// Root and its reciprocal together, for c <= x < inf with c >= 2^-100: the reciprocal of the ROUNDED root
+// is refined from the same v_rsq_f32 value by one Newton step, which is the correctly rounded 1 / root
+// for every x except when the root's significand is all ones (1 / root then lies just above a power
+// of two and the step lands one ulp low); that case adds the ulp back. Checked against 1.0f / sqrtf(x)
+// over all inputs by game_hip_check_exhaustive(5).
+GD void gd_sqrt_rcp_core(float x, float& root, float& inv)
+{
+    float r = __builtin_amdgcn_rsqf(x);
+    float g = x * r, h = 0.5f * r;
+    float d = __builtin_fmaf(-g, g, x);
+    g = __builtin_fmaf(d, h, g);
+    float e = __builtin_fmaf(-g, r, 1.0f);
+    float y = __builtin_fmaf(e, r, r);
+#ifndef GD_NO_ONES_FIX
+    gd_u32 ones = (gd_bits(g) & 0x7fffffu) == 0x7fffffu ? 1u : 0u;
+    y = gd_from_bits(gd_bits(y) + ones);
+#endif
+    root = g; inv = y;
+}
 GD float gd_sqrt(float x)
 {
     if (__builtin_constant_p(x)) return __builtin_sqrtf(x);

@@ -178,7 +178,8 @@ int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out
 /* Exhaustive check, over all 2^32 float bit patterns, that the hardware instruction equals its
  * defining formula: which 0 = v_fract_f32 vs min(x - floor(x), 1 - 2^-24); 1 / 2 = v_max_f32 /
  * v_min_f32 vs "NaN yields the other operand, -0 < +0" against probe constants; 3 / 4 = the short
- * v_rsq_f32 / v_rcp_f32 + fma sequences of the render path vs correctly rounded sqrt(x) and 1/x. */
+ * v_rsq_f32 / v_rcp_f32 + fma sequences of the render path vs correctly rounded sqrt(x) and 1/x; 5 = the joint root / reciprocal-of-root
+ * sequence of the gravity kernel vs sqrtf(x) and 1/sqrtf(x) for 2^-100 <= x < inf. */
 int game_hip_check_exhaustive(int which, uint64_t* mismatches, uint32_t* first_bad);
 
 #ifdef __cplusplus

@@ -43,7 +43,7 @@ def test_device_present(game):
 
 
 # ── hardware instructions vs their defining formulas, all 2^32 inputs ───────────────────
-@pytest.mark.parametrize("which", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("which", [0, 1, 2, 3, 4, 5])
 def test_exhaustive_instruction_semantics(game, which):
     mismatches, first = game.check_exhaustive(which)
     assert mismatches == 0, hex(first)
@@ -244,6 +244,37 @@ def test_c4_8k_feedback_recurrence(game, oracle):
 
 
 # ── particles ───────────────────────────────────────────────────────────────────────────
+def _same_bits_or_nan(a, b):
+    a, b = np.asarray(a, dtype=np.float32), np.asarray(b, dtype=np.float32)
+    return ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all()
+
+
+@pytest.mark.parametrize("bounds", ["none", "reflect"])
+def test_gravity_wild_positions(game, oracle, bounds):
+    """Coincident particles, distances below the 0.001 floor, huge / infinite / NaN coordinates: the tile
+    loops that keep the IEEE results for an infinite squared distance must agree with the oracle."""
+    src = 'cinematic "t" { gravity { rule: 0.5 / (dist + 0.25), damping: 0.9, bounds: %s } layer s { circle() | glow() } }' % bounds
+    cin = game.compile(src).cinematics[0]
+    rng = np.random.default_rng(21)
+    n = 700                                      # three tiles: the wild values sit in the middle one
+    pos = (rng.random((n, 2), dtype=np.float32) * 2 - 1).astype(np.float32)
+    pos[300] = pos[10]                           # coincident pair
+    pos[301] = pos[11] + np.float32(1e-5)        # closer than the floor
+    pos[302] = (1e30, -1e30)
+    pos[303] = (3e38, 3e38)                      # squared distance overflows
+    pos[304] = (np.inf, 0.25)
+    pos[305] = (np.nan, 0.5)
+    pos[306] = (2.0 ** 61, 0.0)                  # beyond the 2^60 guard, finite squared distance
+    p0 = np.concatenate([pos, np.zeros_like(pos)], axis=1)
+    r = cin.renderer(16, 16)
+    r.particles_init(pos)
+    r.particles_step(1 / 60, 2)
+    got_pos, got_vel = r.particles_read()
+    want, _ = oracle.gravity(cin.blob, p0, 1 / 60, 2)
+    assert _same_bits_or_nan(got_pos, want[:, :2]) and _same_bits_or_nan(got_vel, want[:, 2:])
+    r.close()
+
+
 def test_gravity_default_law_bit_exact(game, oracle):
     cin = game.compile(C5_GRAVITY).cinematics[0]
     n = 4096

@@ -273,3 +273,21 @@ def test_unorm8_fma_sequence_equals_division_for_all_bytes():
     e = fma(-q, np.float32(255.0), b)
     got = fma(e, r, q)
     assert np.array_equal(got.view(np.uint32), (b / np.float32(255.0)).view(np.uint32))
+
+
+def test_merged_distance_floor_constant():
+    """The gravity kernel computes max(sqrt(d2), 0.001f) as sqrt(max(d2, c)) with c the smallest float
+    whose correctly rounded root is 0.001f; both forms must agree for every d2."""
+    c = np.array([0x358637BD], dtype=np.uint32).view(np.float32)[0]
+    assert float(c).hex() == "0x1.0c6f7a0000000p-20"
+    floor = np.float32(0.001)
+    assert np.sqrt(c) == floor and np.sqrt(np.nextafter(c, np.float32(0))) < floor
+    near = (np.arange(-2_000_000, 2_000_001, dtype=np.int64) + int(c.view(np.uint32))).astype(np.uint32).view(np.float32)
+    rng = np.random.default_rng(5)
+    wide = rng.integers(0, 0x7F800000, size=4_000_000, dtype=np.uint32).view(np.float32)   # every non-negative finite range
+    special = np.array([0.0, np.inf, np.nan, 1e-45, 1e-38, 3.4e38], dtype=np.float32)
+    for d2 in (near, wide, special):
+        want = np.maximum(np.sqrt(d2), floor)
+        want = np.where(np.isnan(d2), floor, want)          # max(NaN, 0.001) = 0.001 in the render path
+        got = np.sqrt(np.where(np.isnan(d2), c, np.maximum(d2, c)))
+        assert np.array_equal(got.view(np.uint32), want.astype(np.float32).view(np.uint32))

@@ -30,6 +30,15 @@ __device__ __forceinline__ float sqrt_e(float x)   // two residual corrections
     d = __builtin_fmaf(-g, g, x); return __builtin_fmaf(d, h, g);
 }
 
+// reciprocal of the rounded root, refined from the v_rsq_f32 value the root was built from
+__device__ __forceinline__ void root_and_inv(float x, int steps, float& g, float& y)
+{
+    float r = __builtin_amdgcn_rsqf(x); g = x * r; float h = 0.5f * r;
+    float d = __builtin_fmaf(-g, g, x); g = __builtin_fmaf(d, h, g);
+    y = r;
+    for (int i = 0; i < steps; i++) { float e = __builtin_fmaf(-g, y, 1.0f); y = __builtin_fmaf(e, y, y); }
+}
+
 __global__ void probe(int which, unsigned long long* bad /* [256] per biased exponent */)
 {
     unsigned long long total = (unsigned long long)gridDim.x * blockDim.x;
@@ -39,7 +48,11 @@ __global__ void probe(int which, unsigned long long* bad /* [256] per biased exp
         uint32_t ex = (u >> 23) & 0xff;
         if (ex == 0 || ex == 255) continue;
         float got, want;
-        if (which >= 2) { if (u >> 31) continue; want = __builtin_sqrtf(x); got = which == 2 ? sqrt_a(x) : which == 3 ? sqrt_c(x) : which == 4 ? sqrt_d(x) : sqrt_e(x); }
+        if (which >= 6) {
+            if (u >> 31) continue;
+            if (!(x >= 0x1p-100f)) continue;
+            float g; root_and_inv(x, which - 5, g, got); want = 1.0f / g;
+        } else if (which >= 2) { if (u >> 31) continue; want = __builtin_sqrtf(x); got = which == 2 ? sqrt_a(x) : which == 3 ? sqrt_c(x) : which == 4 ? sqrt_d(x) : sqrt_e(x); }
         else { want = 1.0f / x; got = which == 0 ? rcp_a(x) : rcp_b(x); }
         if (__builtin_bit_cast(uint32_t, got) != __builtin_bit_cast(uint32_t, want)) atomicAdd(&bad[ex], 1ull);
     }
@@ -48,8 +61,8 @@ __global__ void probe(int which, unsigned long long* bad /* [256] per biased exp
 int main()
 {
     unsigned long long* d; hipMalloc(&d, 256 * 8);
-    const char* names[] = {"rcp: rcp+1 newton", "rcp: rcp+2 newton", "sqrt: rsq, 1 coupled newton, residual", "sqrt: rsq, residual", "sqrt: v_sqrt + rcp, residual", "sqrt: rsq, 2 residuals"};
-    for (int w = 0; w < 6; w++) {
+    const char* names[] = {"rcp: rcp+1 newton", "rcp: rcp+2 newton", "sqrt: rsq, 1 coupled newton, residual", "sqrt: rsq, residual", "sqrt: v_sqrt + rcp, residual", "sqrt: rsq, 2 residuals", "1/root from rsq, 1 newton", "1/root from rsq, 2 newton", "1/root from rsq, 3 newton"};
+    for (int w = 0; w < 9; w++) {
         hipMemset(d, 0, 256 * 8);
         hipLaunchKernelGGL(probe, dim3(4096), dim3(256), 0, 0, w, d);
         unsigned long long h[256]; hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
