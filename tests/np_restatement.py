@@ -152,3 +152,35 @@ def memory_mix(cur_rgba_float, prev_rgba8, decay):
     """memory.rs:38-45 on float colours; prev is RGBA8."""
     prev = prev_rgba8.astype(np.float32) / F(255.0)
     return mix(cur_rgba_float, prev, F(decay))
+
+
+def gravity_step(p, dt, damping, law, bounds, time):
+    """One step of gravity.rs:70-117 on an (n, 4) float32 array {pos.x, pos.y, vel.x, vel.y}: every
+    particle sums, in index order, dir * law(dist) over the others with dist = max(length(diff), 0.001),
+    dir = diff * (1 / dist) and an fma per accumulated term; then damped velocity, position, bounds.
+    `law(dist, time)` works on float32 arrays. Vectorised over the receiving particle, sequential in j."""
+    p = np.asarray(p, dtype=np.float32)
+    n = p.shape[0]
+    sx, sy = p[:, 0], p[:, 1]
+    fx, fy = np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.float32)
+    idx = np.arange(n)
+    for j in range(n):
+        dx, dy = p[j, 0] - sx, p[j, 1] - sy
+        dist = np.maximum(np.sqrt(fma(dx, dx, dy * dy)), F(0.001))
+        inv = F(1.0) / dist
+        f = np.broadcast_to(np.asarray(law(dist, F(time)), dtype=np.float32), dist.shape)
+        nfx, nfy = fma(dx * inv, f, fx), fma(dy * inv, f, fy)
+        keep = idx == j
+        fx, fy = np.where(keep, fx, nfx), np.where(keep, fy, nfy)
+    vx = p[:, 2] * F(damping) + fx * F(dt)
+    vy = p[:, 3] * F(damping) + fy * F(dt)
+    px, py = sx + vx * F(dt), sy + vy * F(dt)
+    if bounds == "reflect":
+        lo = px < F(-1.0); px = np.where(lo, F(-1.0), px); vx = np.where(lo, -vx, vx)
+        hi = px > F(1.0); px = np.where(hi, F(1.0), px); vx = np.where(hi, -vx, vx)
+        lo = py < F(-1.0); py = np.where(lo, F(-1.0), py); vy = np.where(lo, -vy, vy)
+        hi = py > F(1.0); py = np.where(hi, F(1.0), py); vy = np.where(hi, -vy, vy)
+    elif bounds == "wrap":
+        px = fract((px + F(1.0)) * F(0.5)) * F(2.0) - F(1.0)
+        py = fract((py + F(1.0)) * F(0.5)) * F(2.0) - F(1.0)
+    return np.stack([px, py, vx, vy], axis=1).astype(np.float32)

@@ -291,3 +291,22 @@ def test_merged_distance_floor_constant():
         want = np.where(np.isnan(d2), floor, want)          # max(NaN, 0.001) = 0.001 in the render path
         got = np.sqrt(np.where(np.isnan(d2), c, np.maximum(d2, c)))
         assert np.array_equal(got.view(np.uint32), want.astype(np.float32).view(np.uint32))
+
+
+@pytest.mark.parametrize("bounds", ["reflect", "wrap", "none"])
+def test_gravity_matches_numpy_restatement(game, oracle, bounds):
+    """Independent numpy statement of the particle step (no transcendental in the law) against the C oracle."""
+    src = ('cinematic "t" { gravity { rule: 0.02 / (dist * dist + 0.05) - 0.01, damping: 0.97, bounds: %s } '
+           'layer s { circle() | glow() } }') % bounds
+    cin = game.compile(src).cinematics[0]
+    p = oracle.seed_particles(96)
+    p[:, 2:] = (np.random.default_rng(3).random((96, 2), dtype=np.float32) - np.float32(0.5)) * np.float32(4.0)
+    p[5, :2] = p[6, :2]                                    # a coincident pair exercises the 0.001 floor
+    want = p.copy()
+    t = np.float32(0.0)
+    law = lambda dist, time: np.float32(0.02) / (dist * dist + np.float32(0.05)) - np.float32(0.01)
+    for _ in range(3):
+        t = np.float32(t + np.float32(1 / 60))
+        want = NP.gravity_step(want, np.float32(1 / 60), 0.97, law, bounds, t)
+    got, _ = oracle.gravity(cin.blob, p, 1 / 60, 3)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
