@@ -92,6 +92,13 @@ __global__ void exhaustive_kernel(int which, unsigned long long* mismatches, uin
 int hip_err(const char* what, hipError_t e) { return set_error(GAME_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
 #define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return hip_err(#expr, _e); } while (0)
 
+// Device allocation released on every return path.
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+};
+
 }  // namespace
 
 extern "C" {
@@ -99,36 +106,32 @@ extern "C" {
 int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out)
 {
     if (op < 0 || op >= EV_COUNT || !a || !out || n == 0) return set_error(GAME_E_ARGUMENT, "game_hip_eval: bad argument");
-    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    DevBuf da, db, dout;
     size_t bytes = (size_t)n * 4;
-    HIP_TRY(hipMalloc((void**)&da, bytes));
-    HIP_TRY(hipMalloc((void**)&dout, bytes));
-    HIP_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
-    if (b) { HIP_TRY(hipMalloc((void**)&db, bytes)); HIP_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice)); }
-    hipLaunchKernelGGL(eval_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op, n, da, db, dout);
+    HIP_TRY(da.alloc(bytes));
+    HIP_TRY(dout.alloc(bytes));
+    HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
+    if (b) { HIP_TRY(db.alloc(bytes)); HIP_TRY(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(eval_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op, n, (const float*)da.p, (const float*)db.p, (float*)dout.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
-    (void)hipFree(da); (void)hipFree(dout);
-    if (db) (void)hipFree(db);
+    HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
     return GAME_OK;
 }
 
 int game_hip_check_exhaustive(int which, uint64_t* mismatches, uint32_t* first_bad)
 {
     if (which < 0 || which > 5 || !mismatches || !first_bad) return set_error(GAME_E_ARGUMENT, "game_hip_check_exhaustive: bad argument");
-    unsigned long long* dm = nullptr;
-    uint32_t* df = nullptr;
-    HIP_TRY(hipMalloc((void**)&dm, 8));
-    HIP_TRY(hipMalloc((void**)&df, 4));
-    HIP_TRY(hipMemset(dm, 0, 8));
-    HIP_TRY(hipMemset(df, 0xff, 4));
-    hipLaunchKernelGGL(exhaustive_kernel, dim3(4096), dim3(256), 0, 0, which, dm, df);
+    DevBuf dm, df;
+    HIP_TRY(dm.alloc(8));
+    HIP_TRY(df.alloc(4));
+    HIP_TRY(hipMemset(dm.p, 0, 8));
+    HIP_TRY(hipMemset(df.p, 0xff, 4));
+    hipLaunchKernelGGL(exhaustive_kernel, dim3(4096), dim3(256), 0, 0, which, (unsigned long long*)dm.p, (uint32_t*)df.p);
     HIP_TRY(hipGetLastError());
     unsigned long long m = 0;
-    HIP_TRY(hipMemcpy(&m, dm, 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(first_bad, df, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&m, dm.p, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(first_bad, df.p, 4, hipMemcpyDeviceToHost));
     *mismatches = m;
-    (void)hipFree(dm); (void)hipFree(df);
     return GAME_OK;
 }
 

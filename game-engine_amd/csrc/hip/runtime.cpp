@@ -217,7 +217,7 @@ int launch_frames(game_hip_ctx* c, uint32_t frame0, uint32_t count, uint32_t slo
 int render_impl(game_hip_ctx* c, const float* uniforms, uint32_t nframes, uint32_t row0, uint32_t rows, uint8_t* host)
 {
     if (!c || !uniforms) return set_error(GAME_E_ARGUMENT, "game_hip_render: null argument");
-    if (rows == 0 || row0 + rows > c->h) return set_error(GAME_E_ARGUMENT, "game_hip_render: band outside the image");
+    if (rows == 0 || (uint64_t)row0 + rows > c->h) return set_error(GAME_E_ARGUMENT, "game_hip_render: band outside the image");
     if (nframes == 0) return GAME_OK;
     HIP_TRY(hipSetDevice(c->device));
     int rc = upload_rows(c, uniforms, nframes);
@@ -512,7 +512,7 @@ int game_hip_particles_step(game_hip_ctx* c, float dt, uint32_t steps, uint32_t 
 {
     if (!c) return set_error(GAME_E_ARGUMENT, "game_hip_particles_step: null context");
     if (!c->gfn || !c->px[0]) return set_error(GAME_E_UNSUPPORTED, "particles not initialised (or no gravity block)");
-    if (count == 0 || first + count > c->n) return set_error(GAME_E_ARGUMENT, "game_hip_particles_step: range outside particle set");
+    if (count == 0 || (uint64_t)first + count > c->n) return set_error(GAME_E_ARGUMENT, "game_hip_particles_step: range outside particle set");
     if (count < c->n && steps > 1)
         return set_error(GAME_E_ARGUMENT, "game_hip_particles_step: a partial range advances one step per call (exchange positions between steps)");
     HIP_TRY(hipSetDevice(c->device));
