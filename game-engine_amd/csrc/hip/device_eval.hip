@@ -3,6 +3,8 @@
 // restatement), and exhaustive self-checks of the hardware instructions the device code leans on
 // (v_fract_f32, v_max_f32, v_min_f32) against their defining formulas over all 2^32 inputs.
 #include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
 #include "../front/capi_internal.hpp"
 #include "game_device.h"
 
@@ -11,9 +13,18 @@ using namespace game;
 namespace {
 
 enum EvalOp { EV_FRACT = 0, EV_SIN, EV_COS, EV_ATAN2, EV_HASH2, EV_NOISE2, EV_SIMPLEX, EV_VORONOI, EV_EXP2, EV_LOG2, EV_POW,
-              EV_MAX, EV_MIN, EV_FBM6, EV_SQRT, EV_DIV, EV_SMOOTHSTEP_GLOW, EV_MOD, EV_UNORM8, EV_COUNT };
+              EV_MAX, EV_MIN, EV_FBM6, EV_SQRT, EV_DIV, EV_SMOOTHSTEP_GLOW, EV_MOD, EV_UNORM8, EV_NOISE2_LUT, EV_FBM6_LUT, EV_COUNT };
 
-__global__ void eval_kernel(int op, uint32_t n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out)
+// Fills the lattice-hash table: entry (row iy + 512, column ix + 512) = hash2(ix, iy).
+__global__ void hash_lut_fill(float* __restrict__ table)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+    if (u >= GD_LUT_ROWS) return;
+    table[(size_t)v * GD_LUT_STRIDE + u] = gd_hash2((float)((int)u - GD_LUT_HALF), (float)((int)v - GD_LUT_HALF));
+}
+
+__global__ void eval_kernel(int op, uint32_t n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                            const float* __restrict__ lut)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -38,6 +49,8 @@ __global__ void eval_kernel(int op, uint32_t n, const float* __restrict__ a, con
     case EV_SMOOTHSTEP_GLOW: r = gd_smoothstep(0.005f, -0.005f, x); break;
     case EV_MOD: r = gd_mod(x, y); break;
     case EV_UNORM8: r = gd_unorm8_to_float((gd_u32)x); break;
+    case EV_NOISE2_LUT: r = gd_noise2_lut(x, y, lut); break;
+    case EV_FBM6_LUT: r = gd_fbm2(x, y, 6, 0.5f, 2.0f, lut); break;
     default: break;
     }
     out[i] = r;
@@ -101,6 +114,35 @@ struct DevBuf {
 
 }  // namespace
 
+namespace game {
+
+int hash_lut_for_current_device(const float** table)
+{
+    static std::mutex mu;
+    static std::map<int, float*> tables;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = tables.find(dev);
+    if (it == tables.end()) {
+        float* t = nullptr;
+        const size_t bytes = (size_t)GD_LUT_ROWS * GD_LUT_STRIDE * sizeof(float);
+        HIP_TRY(hipMalloc((void**)&t, bytes));
+        hipError_t e = hipMemset(t, 0, bytes);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(hash_lut_fill, dim3((GD_LUT_ROWS + 255u) / 256u, GD_LUT_ROWS), dim3(256), 0, 0, t);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { (void)hipFree(t); return hip_err("hash_lut_fill", e); }
+        it = tables.emplace(dev, t).first;
+    }
+    *table = it->second;
+    return GAME_OK;
+}
+
+}  // namespace game
+
 extern "C" {
 
 int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out)
@@ -112,7 +154,12 @@ int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out
     HIP_TRY(dout.alloc(bytes));
     HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
     if (b) { HIP_TRY(db.alloc(bytes)); HIP_TRY(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice)); }
-    hipLaunchKernelGGL(eval_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op, n, (const float*)da.p, (const float*)db.p, (float*)dout.p);
+    const float* lut = nullptr;
+    if (op == EV_NOISE2_LUT || op == EV_FBM6_LUT) {
+        int rc = hash_lut_for_current_device(&lut);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(eval_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op, n, (const float*)da.p, (const float*)db.p, (float*)dout.p, lut);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
     return GAME_OK;

@@ -223,6 +223,36 @@ GD float gd_noise2(float px, float py)
     return __builtin_fmaf(gd_mix(gd_mix(a, b, ux), gd_mix(c, d, ux), uy), 2.0f, -1.0f);
 }
 
+// Lattice-hash table. hash2 is a pure function of the lattice point, and a frame touches only a few
+// thousand distinct points per octave while every pixel needs four of them per noise2 call, so the
+// runtime tabulates hash2 over the integer points of [-512, 512]^2 once per device (GD_LUT_STRIDE floats
+// per row, entry (iy + 512, ix + 512)); noise2 then costs one range test, a five-instruction index
+// and four cached loads instead of four hash evaluations. Points outside the table, and a null table,
+// take the arithmetic path; both paths return the same bits because the table is filled by gd_hash2.
+#define GD_LUT_STRIDE 2048u
+#define GD_LUT_ROWS 1025u
+#define GD_LUT_HALF 512
+GD float gd_noise2_lut(float px, float py, const float* __restrict__ lut)
+{
+    float ix = gd_floor(px), iy = gd_floor(py);
+    float fx = gd_fract(px), fy = gd_fract(py);
+    float ux = fx * fx * __builtin_fmaf(-2.0f, fx, 3.0f);
+    float uy = fy * fy * __builtin_fmaf(-2.0f, fy, 3.0f);
+    float a, b, c, d;
+    if (lut != nullptr && gd_abs(ix) <= 511.0f && gd_abs(iy) <= 511.0f) {
+        // ix + (1.5 * 2^23 + 512) is exact and its low 11 significand bits are ix + 512
+        gd_u32 u = gd_bits(ix + 12583424.0f) & 0x7ffu, v = gd_bits(iy + 12583424.0f) & 0x7ffu;
+        const float* t = (const float*)((const char*)lut + ((v << 13) | (u << 2)));
+        a = t[0]; b = t[1]; c = t[GD_LUT_STRIDE]; d = t[GD_LUT_STRIDE + 1u];
+    } else {
+        a = gd_hash2(ix, iy);
+        b = gd_hash2(ix + 1.0f, iy);
+        c = gd_hash2(ix, iy + 1.0f);
+        d = gd_hash2(ix + 1.0f, iy + 1.0f);
+    }
+    return __builtin_fmaf(gd_mix(gd_mix(a, b, ux), gd_mix(c, d, ux), uy), 2.0f, -1.0f);
+}
+
 GD int gd_octaves(float o)   // int(x), clamped to [0, 32]
 {
     if (!(o >= 1.0f)) return 0;
@@ -232,13 +262,13 @@ GD int gd_octaves(float o)   // int(x), clamped to [0, 32]
 
 // fbm2 (glsl.rs:155-169). With a literal octave count the loop unrolls and the amplitude /
 // frequency / max_val recurrences fold to constants.
-GD float gd_fbm2(float px, float py, int octaves, float persistence, float lacunarity)
+GD float gd_fbm2(float px, float py, int octaves, float persistence, float lacunarity, const float* __restrict__ lut = nullptr)
 {
     float value = 0.0f, amplitude = 1.0f, frequency = 1.0f, max_val = 0.0f;
     float qx = px, qy = py;
 #pragma unroll
     for (int i = 0; i < octaves; i++) {
-        value = __builtin_fmaf(gd_noise2(qx * frequency, qy * frequency), amplitude, value);
+        value = __builtin_fmaf(gd_noise2_lut(qx * frequency, qy * frequency, lut), amplitude, value);
         max_val = max_val + amplitude;
         amplitude = amplitude * persistence;
         frequency = frequency * lacunarity;
@@ -323,6 +353,7 @@ struct GdPix {
     float uvx, uvy;        // `uv`
     float time;            // fract(u_time / 120) * 120
     float bass, mid, treble;
+    const float* lut;      // lattice-hash table (uniform; may be null)
 };
 
 // SDF generators: Position -> Sdf
@@ -367,7 +398,7 @@ GD void gb_concentric_waves(GdPix& s, float amplitude, float width, float freque
 }
 GD void gb_fbm(GdPix& s, float scale, int octaves, float persistence, float lacunarity)                 // :320-326
 {
-    s.sdf = gd_fbm2(s.px * scale, s.py * scale, octaves, persistence, lacunarity);
+    s.sdf = gd_fbm2(s.px * scale, s.py * scale, octaves, persistence, lacunarity, s.lut);
 }
 
 // Transforms: Position -> Position
@@ -403,18 +434,18 @@ GD void gb_repeat(GdPix& s, float count)                                        
 }
 GD void gb_domain_warp(GdPix& s, float amount, float freq)                                              // :362-366
 {
-    float n0 = gd_noise2(s.px * freq, s.py * freq);
-    float n1 = gd_noise2(s.px * freq + 5.2f, s.py * freq + 1.3f);
+    float n0 = gd_noise2_lut(s.px * freq, s.py * freq, s.lut);
+    float n1 = gd_noise2_lut(s.px * freq + 5.2f, s.py * freq + 1.3f, s.lut);
     s.px = s.px + n0 * amount; s.py = s.py + n1 * amount;
 }
 GD void gb_curl_noise(GdPix& s, float frequency, float amplitude)                                       // :367-377
 {
     const float eps = 0.001f;
     float bx = s.px * frequency, by = s.py * frequency;
-    float n0 = gd_noise2(bx + 0.0f, by + eps);
-    float n1 = gd_noise2(bx - 0.0f, by - eps);
-    float n2 = gd_noise2(bx + eps, by + 0.0f);
-    float n3 = gd_noise2(bx - eps, by - 0.0f);
+    float n0 = gd_noise2_lut(bx + 0.0f, by + eps, s.lut);
+    float n1 = gd_noise2_lut(bx - 0.0f, by - eps, s.lut);
+    float n2 = gd_noise2_lut(bx + eps, by + 0.0f, s.lut);
+    float n3 = gd_noise2_lut(bx - eps, by - 0.0f, s.lut);
     float cx = (n0 - n1) / (2.0f * eps);
     float cy = -(n2 - n3) / (2.0f * eps);
     float len = gd_length2(cx, cy);
@@ -423,8 +454,8 @@ GD void gb_curl_noise(GdPix& s, float frequency, float amplitude)               
 GD void gb_displace(GdPix& s, float strength)                                                           // :378-381
 {
     float t5 = s.time * 0.5f;
-    float n0 = gd_noise2(s.px * 3.0f + t5, s.py * 3.0f + t5);
-    float n1 = gd_noise2(s.px * 3.0f + 5.2f + t5, s.py * 3.0f + 1.3f + t5);
+    float n0 = gd_noise2_lut(s.px * 3.0f + t5, s.py * 3.0f + t5, s.lut);
+    float n1 = gd_noise2_lut(s.px * 3.0f + 5.2f + t5, s.py * 3.0f + 1.3f + t5, s.lut);
     s.px = s.px + n0 * strength; s.py = s.py + n1 * strength;
 }
 

@@ -36,6 +36,7 @@ struct game_hip_ctx {
     uint32_t* frames = nullptr;
     float* utab_dev = nullptr;
     size_t utab_cap = 0;
+    const float* lut = nullptr;   // lattice-hash table of this device (shared, not owned)
     std::vector<float> utab_host;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.0f;
@@ -63,6 +64,7 @@ struct FrameParams {
     uint32_t w, h, row0, rows;
     uint32_t ustride, slot0, ring, frame0;
     float inv_w, inv_h;
+    const float* lut;
 };
 struct GravityParams {
     const float* xin; const float* yin;
@@ -122,6 +124,14 @@ int compile_hip(const std::string& src, const char* name, std::vector<char>& cod
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
     return GAME_OK;
+}
+
+// True when some stage evaluates noise2 (value noise on the integer lattice).
+bool uses_lattice_noise(const Ir& ir)
+{
+    for (const IrStage& st : ir.stages)
+        if (st.builtin == B_FBM || st.builtin == B_DOMAIN_WARP || st.builtin == B_CURL_NOISE || st.builtin == B_DISPLACE) return true;
+    return false;
 }
 
 // Pixels per lane. Cinematics whose stages are a few dozen instructions per pixel are bound by the
@@ -205,6 +215,7 @@ int launch_frames(game_hip_ctx* c, uint32_t frame0, uint32_t count, uint32_t slo
     P.ustride = c->ustride; P.slot0 = slot0; P.ring = c->ring; P.frame0 = frame0;
     P.inv_w = 1.0f / (float)c->w;
     P.inv_h = 1.0f / (float)c->h;
+    P.lut = c->lut;
     void* args[] = {&P};
     uint32_t gx = (c->w + 256u * c->shape.pixels_per_lane - 1u) / (256u * c->shape.pixels_per_lane);
     uint32_t gy = rows;   // one row per workgroup row; rows <= height <= 65535 is checked at creation
@@ -354,6 +365,10 @@ int game_hip_create(const game_ir* ir, uint32_t width, uint32_t height, int devi
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return fail("hipEventCreate", e);
     rc = ensure_ring(c, c->ir.uses_memory ? 2u : 4u);
     if (rc) { game_hip_destroy(c); return rc; }
+    if (uses_lattice_noise(c->ir) && !getenv("GAME_HIP_NO_LUT")) {   // the variable is a tuning hook
+        rc = hash_lut_for_current_device(&c->lut);
+        if (rc) { game_hip_destroy(c); return rc; }
+    }
     if (c->ir.gravity.present) {
         c->gsource = generate_gravity_kernel(c->ir);
         rc = compile_hip(c->gsource, "game_gravity.hip", code);

@@ -94,6 +94,22 @@ def test_device_division_and_sqrt_are_correctly_rounded(game):
     assert np.array_equal(_bits(game.device_eval("div", tiny, b[:1000])), _bits(tiny / b[:1000]))
 
 
+def test_lattice_hash_table_path_equals_arithmetic_path(game):
+    """noise2 / fbm2 through the per-device hash table against the arithmetic path, on coordinates inside
+    the table, on its edges (|floor| = 511, 512), far outside, and on non-finite inputs."""
+    rng = np.random.default_rng(17)
+    n = 200000
+    parts = [(rng.random((n, 2), dtype=np.float32) * 2 - 1) * np.float32(s) for s in (3.0, 200.0, 515.0, 5000.0, 3.0e7)]
+    edge = np.array([[511.0, 0.5], [511.99, -511.99], [512.0, 3.0], [-512.0, 3.0], [-511.5, 511.5], [-512.01, 0.0], [0.0, 512.5],
+                     [np.nan, 1.0], [1.0, np.nan], [np.inf, 0.0], [0.0, -np.inf], [-0.0, -0.0], [1e-40, -1e-40]], dtype=np.float32)
+    xy = np.concatenate(parts + [edge]).astype(np.float32)
+    x, y = np.ascontiguousarray(xy[:, 0]), np.ascontiguousarray(xy[:, 1])
+    for lut_op, op in (("noise2_lut", "noise2"), ("fbm6_lut", "fbm6")):
+        got, want = game.device_eval(lut_op, x, y), game.device_eval(op, x, y)
+        same = (_bits(got) == _bits(want)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (lut_op, xy[~same][:5], got[~same][:5], want[~same][:5])
+
+
 def test_unorm8_to_float_equals_division_for_all_bytes(game):
     b = np.arange(256, dtype=np.float32)
     assert np.array_equal(_bits(game.device_eval("unorm8", b)), _bits(b / np.float32(255.0)))
