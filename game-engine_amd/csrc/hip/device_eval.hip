@@ -15,12 +15,15 @@ namespace {
 enum EvalOp { EV_FRACT = 0, EV_SIN, EV_COS, EV_ATAN2, EV_HASH2, EV_NOISE2, EV_SIMPLEX, EV_VORONOI, EV_EXP2, EV_LOG2, EV_POW,
               EV_MAX, EV_MIN, EV_FBM6, EV_SQRT, EV_DIV, EV_SMOOTHSTEP_GLOW, EV_MOD, EV_UNORM8, EV_NOISE2_LUT, EV_FBM6_LUT, EV_COUNT };
 
-// Fills the lattice-hash table: entry (row iy + 512, column ix + 512) = hash2(ix, iy).
+// Fills the lattice-hash table: entry (row iy + 512, column ix + 512) = {hash2(ix, iy), hash2(ix, iy + 1)}.
 __global__ void hash_lut_fill(float* __restrict__ table)
 {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
     if (u >= GD_LUT_ROWS) return;
-    table[(size_t)v * GD_LUT_STRIDE + u] = gd_hash2((float)((int)u - GD_LUT_HALF), (float)((int)v - GD_LUT_HALF));
+    const float x = (float)((int)u - GD_LUT_HALF), y = (float)((int)v - GD_LUT_HALF);
+    float* e = table + ((size_t)v * GD_LUT_STRIDE + u) * 2u;
+    e[0] = gd_hash2(x, y);
+    e[1] = gd_hash2(x, y + 1.0f);
 }
 
 __global__ void eval_kernel(int op, uint32_t n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
@@ -126,7 +129,7 @@ int hash_lut_for_current_device(const float** table)
     auto it = tables.find(dev);
     if (it == tables.end()) {
         float* t = nullptr;
-        const size_t bytes = (size_t)GD_LUT_ROWS * GD_LUT_STRIDE * sizeof(float);
+        const size_t bytes = (size_t)GD_LUT_ROWS * GD_LUT_STRIDE * 2u * sizeof(float);
         HIP_TRY(hipMalloc((void**)&t, bytes));
         hipError_t e = hipMemset(t, 0, bytes);
         if (e == hipSuccess) {

@@ -14,6 +14,7 @@
 
 typedef unsigned int gd_u32;
 typedef gd_u32 gd_u32x4 __attribute__((ext_vector_type(4)));
+typedef float gd_f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));   // 16-byte load at 8-byte alignment
 
 // ── scalar helpers ──────────────────────────────────────────────────────────────────────
 GD gd_u32 gd_bits(float f) { return __builtin_bit_cast(gd_u32, f); }
@@ -225,32 +226,73 @@ GD float gd_noise2(float px, float py)
 
 // Lattice-hash table. hash2 is a pure function of the lattice point, and a frame touches only a few
 // thousand distinct points per octave while every pixel needs four of them per noise2 call, so the
-// runtime tabulates hash2 over the integer points of [-512, 512]^2 once per device (GD_LUT_STRIDE floats
-// per row, entry (iy + 512, ix + 512)); noise2 then costs one range test, a five-instruction index
-// and four cached loads instead of four hash evaluations. Points outside the table, and a null table,
+// runtime tabulates hash2 over the integer points of [-512, 512]^2 once per device. Entry (iy + 512,
+// ix + 512) holds the pair {hash2(ix, iy), hash2(ix, iy + 1)} (GD_LUT_STRIDE pairs per row), so the four
+// corners of a cell are one 16-byte load; noise2 then costs one range test, a five-instruction index
+// and that load instead of four hash evaluations. Points outside the table, and a null table,
 // take the arithmetic path; both paths return the same bits because the table is filled by gd_hash2.
 #define GD_LUT_STRIDE 2048u
 #define GD_LUT_ROWS 1025u
 #define GD_LUT_HALF 512
+// One noise2 evaluation split in two, so that callers needing several values (the fbm octaves, the two
+// components of a warp) can test all their lattice cells first, issue all table loads back to back, and
+// only then combine: the loads of one call overlap instead of each waiting out its own latency.
+struct GdCell {
+    float ix, iy;    // lattice cell
+    float ux, uy;    // Hermite weights of the fractional part
+    gd_u32 off;      // byte offset of entry (iy, ix) in the table (valid when ok)
+    bool ok;         // all four corners are inside the table
+};
+GD GdCell gd_cell(float px, float py)
+{
+    GdCell c;
+    c.ix = gd_floor(px); c.iy = gd_floor(py);
+    float fx = gd_fract(px), fy = gd_fract(py);
+    c.ux = fx * fx * __builtin_fmaf(-2.0f, fx, 3.0f);
+    c.uy = fy * fy * __builtin_fmaf(-2.0f, fy, 3.0f);
+    c.ok = gd_abs(c.ix) <= 511.0f && gd_abs(c.iy) <= 511.0f;
+    // ix + (1.5 * 2^23 + 512) is exact and its low 11 significand bits are ix + 512
+    gd_u32 u = gd_bits(c.ix + 12583424.0f) & 0x7ffu, v = gd_bits(c.iy + 12583424.0f) & 0x7ffu;
+    c.off = (v << 14) | (u << 3);
+    return c;
+}
+struct GdCorners { float a, b, c, d; };
+GD GdCorners gd_corners_load(const GdCell& c, const float* __restrict__ lut)
+{
+    const gd_f32x4_a8 t = *(const gd_f32x4_a8*)((const char*)lut + c.off);   // {h(x,y), h(x,y+1), h(x+1,y), h(x+1,y+1)}
+    GdCorners k;
+    k.a = t[0]; k.c = t[1]; k.b = t[2]; k.d = t[3];
+    return k;
+}
+GD GdCorners gd_corners_hash(const GdCell& c)
+{
+    GdCorners k;
+    k.a = gd_hash2(c.ix, c.iy);
+    k.b = gd_hash2(c.ix + 1.0f, c.iy);
+    k.c = gd_hash2(c.ix, c.iy + 1.0f);
+    k.d = gd_hash2(c.ix + 1.0f, c.iy + 1.0f);
+    return k;
+}
+GD float gd_noise2_combine(const GdCell& c, const GdCorners& k)
+{
+    return __builtin_fmaf(gd_mix(gd_mix(k.a, k.b, c.ux), gd_mix(k.c, k.d, c.ux), c.uy), 2.0f, -1.0f);
+}
 GD float gd_noise2_lut(float px, float py, const float* __restrict__ lut)
 {
-    float ix = gd_floor(px), iy = gd_floor(py);
-    float fx = gd_fract(px), fy = gd_fract(py);
-    float ux = fx * fx * __builtin_fmaf(-2.0f, fx, 3.0f);
-    float uy = fy * fy * __builtin_fmaf(-2.0f, fy, 3.0f);
-    float a, b, c, d;
-    if (lut != nullptr && gd_abs(ix) <= 511.0f && gd_abs(iy) <= 511.0f) {
-        // ix + (1.5 * 2^23 + 512) is exact and its low 11 significand bits are ix + 512
-        gd_u32 u = gd_bits(ix + 12583424.0f) & 0x7ffu, v = gd_bits(iy + 12583424.0f) & 0x7ffu;
-        const float* t = (const float*)((const char*)lut + ((v << 13) | (u << 2)));
-        a = t[0]; b = t[1]; c = t[GD_LUT_STRIDE]; d = t[GD_LUT_STRIDE + 1u];
-    } else {
-        a = gd_hash2(ix, iy);
-        b = gd_hash2(ix + 1.0f, iy);
-        c = gd_hash2(ix, iy + 1.0f);
-        d = gd_hash2(ix + 1.0f, iy + 1.0f);
-    }
-    return __builtin_fmaf(gd_mix(gd_mix(a, b, ux), gd_mix(c, d, ux), uy), 2.0f, -1.0f);
+    GdCell c = gd_cell(px, py);
+    GdCorners k;
+    if (lut != nullptr && c.ok) k = gd_corners_load(c, lut);
+    else k = gd_corners_hash(c);
+    return gd_noise2_combine(c, k);
+}
+// Two values at once (the pairs of domain_warp, displace and the central differences of curl_noise).
+GD void gd_noise2_pair_lut(float ax, float ay, float bx, float by, const float* __restrict__ lut, float& na, float& nb)
+{
+    GdCell ca = gd_cell(ax, ay), cb = gd_cell(bx, by);
+    GdCorners ka, kb;
+    if (lut != nullptr && ca.ok && cb.ok) { ka = gd_corners_load(ca, lut); kb = gd_corners_load(cb, lut); }
+    else { ka = gd_corners_hash(ca); kb = gd_corners_hash(cb); }
+    na = gd_noise2_combine(ca, ka); nb = gd_noise2_combine(cb, kb);
 }
 
 GD int gd_octaves(float o)   // int(x), clamped to [0, 32]
@@ -264,6 +306,37 @@ GD int gd_octaves(float o)   // int(x), clamped to [0, 32]
 // frequency / max_val recurrences fold to constants.
 GD float gd_fbm2(float px, float py, int octaves, float persistence, float lacunarity, const float* __restrict__ lut = nullptr)
 {
+    if (lut != nullptr && __builtin_constant_p(octaves) && octaves >= 1 && octaves <= 8) {
+        // literal octave count: all cells first, then (when every cell is inside the table) all loads, then the sum
+        GdCell cell[8];
+        float amp[8];
+        float amplitude = 1.0f, frequency = 1.0f, max_val = 0.0f, qx = px, qy = py;
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < octaves; i++) {
+            cell[i] = gd_cell(qx * frequency, qy * frequency);
+            ok = ok && cell[i].ok;
+            amp[i] = amplitude;
+            max_val = max_val + amplitude;
+            amplitude = amplitude * persistence;
+            frequency = frequency * lacunarity;
+            float nx = __builtin_fmaf(qx, 0.8f, -(qy * 0.6f));
+            float ny = __builtin_fmaf(qx, 0.6f, qy * 0.8f);
+            qx = nx; qy = ny;
+        }
+        GdCorners k[8];
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < octaves; i++) k[i] = gd_corners_load(cell[i], lut);
+        } else {
+#pragma unroll
+            for (int i = 0; i < octaves; i++) k[i] = gd_corners_hash(cell[i]);
+        }
+        float value = 0.0f;
+#pragma unroll
+        for (int i = 0; i < octaves; i++) value = __builtin_fmaf(gd_noise2_combine(cell[i], k[i]), amp[i], value);
+        return value * gd_rcp(max_val);
+    }
     float value = 0.0f, amplitude = 1.0f, frequency = 1.0f, max_val = 0.0f;
     float qx = px, qy = py;
 #pragma unroll
@@ -434,18 +507,17 @@ GD void gb_repeat(GdPix& s, float count)                                        
 }
 GD void gb_domain_warp(GdPix& s, float amount, float freq)                                              // :362-366
 {
-    float n0 = gd_noise2_lut(s.px * freq, s.py * freq, s.lut);
-    float n1 = gd_noise2_lut(s.px * freq + 5.2f, s.py * freq + 1.3f, s.lut);
+    float n0, n1;
+    gd_noise2_pair_lut(s.px * freq, s.py * freq, s.px * freq + 5.2f, s.py * freq + 1.3f, s.lut, n0, n1);
     s.px = s.px + n0 * amount; s.py = s.py + n1 * amount;
 }
 GD void gb_curl_noise(GdPix& s, float frequency, float amplitude)                                       // :367-377
 {
     const float eps = 0.001f;
     float bx = s.px * frequency, by = s.py * frequency;
-    float n0 = gd_noise2_lut(bx + 0.0f, by + eps, s.lut);
-    float n1 = gd_noise2_lut(bx - 0.0f, by - eps, s.lut);
-    float n2 = gd_noise2_lut(bx + eps, by + 0.0f, s.lut);
-    float n3 = gd_noise2_lut(bx - eps, by - 0.0f, s.lut);
+    float n0, n1, n2, n3;
+    gd_noise2_pair_lut(bx + 0.0f, by + eps, bx - 0.0f, by - eps, s.lut, n0, n1);
+    gd_noise2_pair_lut(bx + eps, by + 0.0f, bx - eps, by - 0.0f, s.lut, n2, n3);
     float cx = (n0 - n1) / (2.0f * eps);
     float cy = -(n2 - n3) / (2.0f * eps);
     float len = gd_length2(cx, cy);
@@ -454,8 +526,8 @@ GD void gb_curl_noise(GdPix& s, float frequency, float amplitude)               
 GD void gb_displace(GdPix& s, float strength)                                                           // :378-381
 {
     float t5 = s.time * 0.5f;
-    float n0 = gd_noise2_lut(s.px * 3.0f + t5, s.py * 3.0f + t5, s.lut);
-    float n1 = gd_noise2_lut(s.px * 3.0f + 5.2f + t5, s.py * 3.0f + 1.3f + t5, s.lut);
+    float n0, n1;
+    gd_noise2_pair_lut(s.px * 3.0f + t5, s.py * 3.0f + t5, s.px * 3.0f + 5.2f + t5, s.py * 3.0f + 1.3f + t5, s.lut, n0, n1);
     s.px = s.px + n0 * strength; s.py = s.py + n1 * strength;
 }
 
