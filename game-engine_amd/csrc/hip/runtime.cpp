@@ -37,6 +37,7 @@ struct game_hip_ctx {
     float* utab_dev = nullptr;
     size_t utab_cap = 0;
     const float* lut = nullptr;   // lattice-hash table of this device (shared, not owned)
+    const float* vlut = nullptr;  // voronoi feature-point table of this device (shared, not owned)
     std::vector<float> utab_host;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.0f;
@@ -65,6 +66,7 @@ struct FrameParams {
     uint32_t ustride, slot0, ring, frame0;
     float inv_w, inv_h;
     const float* lut;
+    const float* vlut;
 };
 struct GravityParams {
     const float* xin; const float* yin;
@@ -124,6 +126,13 @@ int compile_hip(const std::string& src, const char* name, std::vector<char>& cod
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
     return GAME_OK;
+}
+
+bool uses_builtin(const Ir& ir, uint16_t id)
+{
+    for (const IrStage& st : ir.stages)
+        if (st.builtin == id) return true;
+    return false;
 }
 
 // True when some stage evaluates noise2 (value noise on the integer lattice).
@@ -216,6 +225,7 @@ int launch_frames(game_hip_ctx* c, uint32_t frame0, uint32_t count, uint32_t slo
     P.inv_w = 1.0f / (float)c->w;
     P.inv_h = 1.0f / (float)c->h;
     P.lut = c->lut;
+    P.vlut = c->vlut;
     void* args[] = {&P};
     uint32_t gx = (c->w + 256u * c->shape.pixels_per_lane - 1u) / (256u * c->shape.pixels_per_lane);
     uint32_t gy = rows;   // one row per workgroup row; rows <= height <= 65535 is checked at creation
@@ -366,7 +376,11 @@ int game_hip_create(const game_ir* ir, uint32_t width, uint32_t height, int devi
     rc = ensure_ring(c, c->ir.uses_memory ? 2u : 4u);
     if (rc) { game_hip_destroy(c); return rc; }
     if (uses_lattice_noise(c->ir) && !getenv("GAME_HIP_NO_LUT")) {   // the variable is a tuning hook
-        rc = hash_lut_for_current_device(&c->lut);
+        rc = lut_for_current_device(0, &c->lut);
+        if (rc) { game_hip_destroy(c); return rc; }
+    }
+    if (uses_builtin(c->ir, B_VORONOI) && !getenv("GAME_HIP_NO_LUT")) {
+        rc = lut_for_current_device(1, &c->vlut);
         if (rc) { game_hip_destroy(c); return rc; }
     }
     if (c->ir.gravity.present) {
