@@ -197,6 +197,9 @@ def run_frames(args, torch, rank, world, local, key):
                                    "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
                                    "kernel": "game_frame", "avg_launch_ms": round(sec * 1e3, 4), "pixels_per_launch": px_launch,
                                    "bytes_per_pixel": cfg["bytes_px"]}
+            if cfg["bound"] == "valu" and not os.environ.get("GAME_HIP_NO_LUT"):
+                out["roofline"]["note"] = ("lattice hashes / voronoi points are read from per-device tables, so the algorithmic flop rate "
+                                           "can exceed the arithmetic peak; valu_issue_frac is the share of VALU issue slots actually used")
             if pmc:
                 # share of the VALU issue slots (one wave64 instruction per 2 cycles per SIMD) this launch used
                 out["roofline"]["valu_issue_frac"] = round(pmc["waves_per_launch"] * pmc["valu_instructions_per_wave"] * 2.0 / (SIMDS * CLOCK_HZ * sec), 4)
