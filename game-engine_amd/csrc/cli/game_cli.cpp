@@ -7,13 +7,18 @@
 //               [--cinematic I] [--out PREFIX] [--particles N --steps S]
 //                                        the render command the reference lacks (its frames are drawn by a
 //                                        browser): renders N frames with u_time = k / F on the GPU; with
-//                                        --out writes PREFIX_00000.ppm ... (binary P6, RGB of the RGBA8 frame)
+//                                        --out writes PREFIX_00000.ppm ... (binary P6, RGB of the RGBA8 frame),
+//                                        or PREFIX_00000.png (8-bit RGBA, stored deflate blocks) with --png
+//   game compare A B [--threshold T]     two frames (.ppm or .png written by this tool): share of pixels whose
+//                                        channels all differ by <= T (the measure of snapshot.rs:240-258,
+//                                        default T = 2), max |difference| and PSNR; exit 1 when not identical
 //   game ir     a.game                   resolved IR of every cinematic as JSON
 //   game kernel a.game [--size WxH]      generated HIP source of the fused per-pixel kernel
 //   game builtins                        the builtin table (name, input -> output state, parameters)
 //
 // Only the C ABI of include/game_hip.h is used.
 #include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -43,13 +48,16 @@ int usage()
             "usage: game check FILE...\n"
             "       game render FILE --hip [--size WxH] [--frames N] [--fps F] [--batch B] [--device D]\n"
             "                   [--cinematic I] [--out PREFIX] [--particles N --steps S]\n"
+            "                   [--png]\n"
+            "       game compare A B [--threshold T]\n"
             "       game ir FILE | game kernel FILE [--size WxH] | game builtins\n");
     return 2;
 }
 
 struct Args {
     std::vector<std::string> files;
-    bool hip = false;
+    bool hip = false, png = false;
+    int threshold = 2;
     uint32_t w = 1920, h = 1080, frames = 60, batch = 16, cinematic = 0, particles = 0, steps = 1;
     double fps = 60.0;
     int device = 0;
@@ -65,6 +73,8 @@ bool parse_args(int argc, char** argv, int first, Args& a)
             return argv[++i];
         };
         if (s == "--hip") a.hip = true;
+        else if (s == "--png") a.png = true;
+        else if (s == "--threshold") { const char* v = value("--threshold"); if (!v) return false; a.threshold = atoi(v); }
         else if (s == "--size") {
             const char* v = value("--size");
             if (!v || sscanf(v, "%ux%u", &a.w, &a.h) != 2) { fprintf(stderr, "game: --size wants WxH\n"); return false; }
@@ -130,6 +140,153 @@ bool write_ppm(const std::string& path, const uint8_t* rgba, uint32_t w, uint32_
     return true;
 }
 
+// ── PNG (8-bit RGBA, no compression: zlib stream of stored blocks) ───────────────────────────────────────
+uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n)
+{
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        ready = true;
+    }
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+    return crc;
+}
+
+void put_be32(std::vector<uint8_t>& v, uint32_t x) { for (int s = 24; s >= 0; s -= 8) v.push_back((uint8_t)(x >> s)); }
+
+void png_chunk(std::vector<uint8_t>& out, const char* type, const std::vector<uint8_t>& data)
+{
+    put_be32(out, (uint32_t)data.size());
+    size_t start = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), data.begin(), data.end());
+    put_be32(out, crc32_update(0xffffffffu, out.data() + start, out.size() - start) ^ 0xffffffffu);
+}
+
+bool write_png(const std::string& path, const uint8_t* rgba, uint32_t w, uint32_t h)
+{
+    std::vector<uint8_t> raw;                       // filter byte 0 + row, per row
+    raw.reserve((size_t)h * ((size_t)w * 4 + 1));
+    for (uint32_t y = 0; y < h; ++y) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgba + (size_t)y * w * 4, rgba + (size_t)(y + 1) * w * 4);
+    }
+    std::vector<uint8_t> z = {0x78, 0x01};
+    uint32_t a = 1, b = 0;                          // Adler-32 of the raw data
+    for (size_t i = 0; i < raw.size();) {
+        size_t n = raw.size() - i < 5552 ? raw.size() - i : 5552;
+        for (size_t k = 0; k < n; ++k) { a += raw[i + k]; b += a; }
+        a %= 65521u; b %= 65521u;
+        i += n;
+    }
+    for (size_t i = 0; i < raw.size() || i == 0;) {
+        size_t n = raw.size() - i < 65535 ? raw.size() - i : 65535;
+        z.push_back(i + n >= raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xff)); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xff)); z.push_back((uint8_t)((~n >> 8) & 0xff));
+        z.insert(z.end(), raw.begin() + i, raw.begin() + i + n);
+        i += n;
+        if (n == 0) break;
+    }
+    put_be32(z, (b << 16) | a);
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, w); put_be32(ihdr, h);
+    ihdr.insert(ihdr.end(), {8, 6, 0, 0, 0});       // 8 bits, RGBA, deflate, no filter method, no interlace
+    png_chunk(out, "IHDR", ihdr);
+    png_chunk(out, "IDAT", z);
+    png_chunk(out, "IEND", {});
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    fclose(f);
+    return ok;
+}
+
+// Reads a frame written by this tool: binary PPM (RGB) or the stored-block PNG above (RGBA). Alpha of a PPM is 255.
+bool read_frame(const std::string& path, std::vector<uint8_t>& rgba, uint32_t& w, uint32_t& h)
+{
+    std::string data;
+    if (!read_file(path, data)) return false;
+    const uint8_t* p = (const uint8_t*)data.data();
+    if (data.size() > 11 && data[0] == 'P' && data[1] == '6') {
+        int maxv = 0, used = 0;
+        if (sscanf(data.c_str(), "P6 %u %u %d%n", &w, &h, &maxv, &used) != 3 || maxv != 255) return false;
+        size_t off = (size_t)used + 1;
+        if (data.size() < off + (size_t)w * h * 3) return false;
+        rgba.resize((size_t)w * h * 4);
+        for (size_t i = 0; i < (size_t)w * h; ++i) {
+            rgba[4 * i] = p[off + 3 * i]; rgba[4 * i + 1] = p[off + 3 * i + 1]; rgba[4 * i + 2] = p[off + 3 * i + 2]; rgba[4 * i + 3] = 255;
+        }
+        return true;
+    }
+    if (data.size() < 8 + 25 || memcmp(p, "\x89PNG\r\n\x1a\n", 8) != 0) return false;
+    auto be32 = [&](size_t o) { return ((uint32_t)p[o] << 24) | ((uint32_t)p[o + 1] << 16) | ((uint32_t)p[o + 2] << 8) | p[o + 3]; };
+    std::vector<uint8_t> z;
+    bool have_ihdr = false;
+    for (size_t o = 8; o + 12 <= data.size();) {
+        uint32_t len = be32(o);
+        if (o + 12 + len > data.size()) return false;
+        if (!memcmp(p + o + 4, "IHDR", 4)) {
+            w = be32(o + 8); h = be32(o + 12);
+            if (p[o + 16] != 8 || p[o + 17] != 6 || p[o + 20] != 0) return false;
+            have_ihdr = true;
+        } else if (!memcmp(p + o + 4, "IDAT", 4)) z.insert(z.end(), p + o + 8, p + o + 8 + len);
+        o += 12 + len;
+    }
+    if (!have_ihdr || z.size() < 6) return false;
+    std::vector<uint8_t> raw;
+    for (size_t i = 2; i + 5 <= z.size();) {          // stored blocks only (what write_png emits)
+        if ((z[i] & 6) != 0) return false;
+        bool last = z[i] & 1;
+        size_t n = z[i + 1] | ((size_t)z[i + 2] << 8);
+        if (i + 5 + n > z.size()) return false;
+        raw.insert(raw.end(), z.begin() + i + 5, z.begin() + i + 5 + n);
+        i += 5 + n;
+        if (last) break;
+    }
+    if (raw.size() != (size_t)h * ((size_t)w * 4 + 1)) return false;
+    rgba.resize((size_t)w * h * 4);
+    for (uint32_t y = 0; y < h; ++y) {
+        if (raw[(size_t)y * (w * 4 + 1)] != 0) return false;
+        memcpy(rgba.data() + (size_t)y * w * 4, raw.data() + (size_t)y * (w * 4 + 1) + 1, (size_t)w * 4);
+    }
+    return true;
+}
+
+int cmd_compare(const Args& a)
+{
+    if (a.files.size() != 2) return usage();
+    std::vector<uint8_t> x, y;
+    uint32_t w0 = 0, h0 = 0, w1 = 0, h1 = 0;
+    if (!read_frame(a.files[0], x, w0, h0)) { fprintf(stderr, "game compare: cannot read %s\n", a.files[0].c_str()); return 2; }
+    if (!read_frame(a.files[1], y, w1, h1)) { fprintf(stderr, "game compare: cannot read %s\n", a.files[1].c_str()); return 2; }
+    if (w0 != w1 || h0 != h1) { fprintf(stderr, "game compare: sizes differ (%ux%u vs %ux%u)\n", w0, h0, w1, h1); return 1; }
+    size_t px = (size_t)w0 * h0, matching = 0;
+    int max_abs = 0;
+    double sq = 0.0;
+    for (size_t i = 0; i < px; ++i) {
+        bool ok = true;
+        for (int c = 0; c < 3; ++c) {                // RGB, as compare_pixels in snapshot.rs:240-258
+            int d = abs((int)x[4 * i + c] - (int)y[4 * i + c]);
+            if (d > a.threshold) ok = false;
+            if (d > max_abs) max_abs = d;
+            sq += (double)d * d;
+        }
+        matching += ok;
+    }
+    double mse = sq / (3.0 * (double)px);
+    if (mse == 0.0) printf("similarity %.4f %% (threshold %d), max abs diff 0, PSNR inf dB\n", 100.0 * matching / (double)px, a.threshold);
+    else printf("similarity %.4f %% (threshold %d), max abs diff %d, PSNR %.2f dB\n", 100.0 * matching / (double)px, a.threshold, max_abs,
+                10.0 * log10(255.0 * 255.0 / mse));
+    return max_abs == 0 ? 0 : 1;
+}
+
 int cmd_render(const Args& a)
 {
     if (a.files.size() != 1) return usage();
@@ -173,8 +330,9 @@ int cmd_render(const Args& a)
             device_ms += ms;
             for (uint32_t k = 0; k < n && !host.empty(); ++k) {
                 char name[32];
-                snprintf(name, sizeof name, "_%05u.ppm", done + k);
-                if (!write_ppm(a.out + name, host.data() + (size_t)k * a.w * a.h * 4, a.w, a.h)) {
+                snprintf(name, sizeof name, a.png ? "_%05u.png" : "_%05u.ppm", done + k);
+                const uint8_t* frame = host.data() + (size_t)k * a.w * a.h * 4;
+                if (!(a.png ? write_png(a.out + name, frame, a.w, a.h) : write_ppm(a.out + name, frame, a.w, a.h))) {
                     fprintf(stderr, "game render: cannot write %s%s\n", a.out.c_str(), name);
                     ok = false;
                     break;
@@ -239,6 +397,7 @@ int main(int argc, char** argv)
     if (!parse_args(argc, argv, 2, a)) return 2;
     if (cmd == "check") return cmd_check(a);
     if (cmd == "render") return cmd_render(a);
+    if (cmd == "compare") return cmd_compare(a);
     if (cmd == "ir") return cmd_ir(a);
     if (cmd == "kernel") return cmd_kernel(a);
     if (cmd == "builtins") return cmd_builtins();

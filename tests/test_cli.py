@@ -47,6 +47,60 @@ def test_render_requires_backend_flag(tmp_path):
     assert r.returncode == 2 and "--hip" in r.stderr
 
 
+def test_compare_reports_similarity_max_diff_and_psnr(tmp_path):
+    a = np.random.default_rng(0).integers(0, 256, (8, 12, 3), dtype=np.uint8)
+    b = a.copy()
+    b[3, 4, 1] ^= 4                                   # one channel of one pixel off by 4
+    for name, img in (("a", a), ("b", b)):
+        (tmp_path / f"{name}.ppm").write_bytes(b"P6\n12 8\n255\n" + img.tobytes())
+    r = run("compare", str(tmp_path / "a.ppm"), str(tmp_path / "a.ppm"))
+    assert r.returncode == 0 and "similarity 100.0000 %" in r.stdout and "max abs diff 0" in r.stdout
+    r = run("compare", str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm"))
+    # snapshot.rs:240-258: a pixel matches when every RGB channel differs by at most the threshold
+    assert r.returncode == 1 and "similarity 98.9583 %" in r.stdout and "max abs diff 4" in r.stdout
+    mse = 16.0 / (8 * 12 * 3)
+    assert f"PSNR {10 * np.log10(255.0 ** 2 / mse):.2f} dB" in r.stdout
+    r = run("compare", str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm"), "--threshold", "4")
+    assert "similarity 100.0000 %" in r.stdout and r.returncode == 1
+
+
+def _decode_png(path):
+    """Minimal PNG reader (8-bit RGBA, filter 0 rows) through zlib, independent of the tool's own reader."""
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    o, idat, w, h = 8, b"", 0, 0
+    while o < len(data):
+        n, kind = struct.unpack(">I4s", data[o:o + 8])
+        body = data[o + 8:o + 8 + n]
+        assert struct.unpack(">I", data[o + 8 + n:o + 12 + n])[0] == zlib.crc32(kind + body)
+        if kind == b"IHDR":
+            w, h, depth, colour = struct.unpack(">IIBB", body[:10])
+            assert (depth, colour) == (8, 6)
+        elif kind == b"IDAT":
+            idat += body
+        o += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, w * 4 + 1)
+    assert np.all(raw[:, 0] == 0)
+    return raw[:, 1:].reshape(h, w, 4)
+
+
+@pytest.mark.gpu
+def test_render_png_sink_and_compare(tmp_path, game):
+    f = tmp_path / "g.game"
+    f.write_text(C1_HELLO)
+    out = str(tmp_path / "p")
+    assert run("render", str(f), "--hip", "--size", "300x70", "--frames", "2", "--out", out, "--png").returncode == 0
+    assert run("render", str(f), "--hip", "--size", "300x70", "--frames", "2", "--out", out).returncode == 0
+    cin = game.compile(C1_HELLO).cinematics[0]
+    want = cin.renderer(300, 70).render(cin.uniform_rows([0.0, 1 / 60.0], 300, 70))
+    for k in range(2):
+        assert np.array_equal(_decode_png(f"{out}_{k:05d}.png"), want[k])
+        r = run("compare", f"{out}_{k:05d}.png", f"{out}_{k:05d}.ppm")
+        assert r.returncode == 0 and "max abs diff 0" in r.stdout
+
+
 @pytest.mark.gpu
 def test_render_writes_frames_equal_to_the_library(tmp_path, game):
     f = tmp_path / "g.game"
