@@ -60,6 +60,7 @@ def _load():
         "game_ir_default_uniforms": (None, [vp, f32, u32, u32, vp]),
         "game_hip_device_count": (c.c_int, [c.POINTER(c.c_int)]),
         "game_hip_create": (c.c_int, [vp, u32, u32, c.c_int, c.POINTER(vp)]),
+        "game_hip_create_ex": (c.c_int, [vp, u32, u32, c.c_int, u32, c.POINTER(vp)]),
         "game_hip_destroy": (None, [vp]),
         "game_hip_set_ring": (c.c_int, [vp, u32]),
         "game_hip_render": (c.c_int, [vp, vp, u32, vp]),
@@ -71,6 +72,7 @@ def _load():
         "game_hip_last_kernel_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(u32)]),
         "game_hip_kernel_source": (c.c_char_p, [vp]),
         "game_hip_compile_only": (c.c_int, [vp, c.POINTER(sz)]),
+        "game_hip_compile_only_ex": (c.c_int, [vp, u32, c.POINTER(sz)]),
         "game_hip_dump_code": (c.c_int, [vp, c.c_char_p]),
         "game_hip_particles_init": (c.c_int, [vp, u32, vp, vp]),
         "game_hip_particles_seed": (c.c_int, [vp, u32, u64]),
@@ -89,6 +91,9 @@ def _load():
 
 
 lib, EXPORTED_SYMBOLS = _load()
+
+
+SEMANTICS = {"glsl": 0, "wgsl": 1}   # GAME_HIP_SEMANTICS_WGSL
 
 
 def _check(rc):
@@ -155,18 +160,19 @@ class Cinematic:
                 rows[:, BU_COUNT + names.index(key)] = np.asarray(val, dtype=np.float32)
         return rows
 
-    def compile_only(self):
+    def compile_only(self, semantics="glsl"):
         """hiprtc-compiles the generated kernels for gfx950 without a device; returns code bytes."""
         n = ctypes.c_size_t()
-        _check(lib.game_hip_compile_only(self._h, ctypes.byref(n)))
+        _check(lib.game_hip_compile_only_ex(self._h, SEMANTICS[semantics], ctypes.byref(n)))
         return n.value
 
     def dump_code(self, path_prefix):
         """Writes the generated kernel source and gfx950 code object next to `path_prefix`."""
         _check(lib.game_hip_dump_code(self._h, path_prefix.encode()))
 
-    def renderer(self, w, h, device=0):
-        return Renderer(self, w, h, device)
+    def renderer(self, w, h, device=0, semantics="glsl"):
+        """semantics: "glsl" = the reference's WebGL2 wording of the builtins (default), "wgsl" = its WebGPU wording."""
+        return Renderer(self, w, h, device, semantics)
 
 
 class Program:
@@ -247,11 +253,11 @@ def device_count():
 class Renderer:
     """GPU context for one cinematic at one resolution (reference: GameRendererGL, runtime/helpers.rs:131-241)."""
 
-    def __init__(self, cinematic, w, h, device=0):
+    def __init__(self, cinematic, w, h, device=0, semantics="glsl"):
         self.cinematic = cinematic
         self.w, self.h = w, h
         h_ = ctypes.c_void_p()
-        _check(lib.game_hip_create(cinematic._h, w, h, device, ctypes.byref(h_)))
+        _check(lib.game_hip_create_ex(cinematic._h, w, h, device, SEMANTICS[semantics], ctypes.byref(h_)))
         self._h = h_
 
     def close(self):

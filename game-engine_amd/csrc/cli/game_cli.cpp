@@ -8,7 +8,9 @@
 //                                        the render command the reference lacks (its frames are drawn by a
 //                                        browser): renders N frames with u_time = k / F on the GPU; with
 //                                        --out writes PREFIX_00000.ppm ... (binary P6, RGB of the RGBA8 frame),
-//                                        or PREFIX_00000.png (8-bit RGBA, stored deflate blocks) with --png
+//                                        or PREFIX_00000.png (8-bit RGBA, stored deflate blocks) with --png;
+//                                        --semantics wgsl renders the builtins as the reference's WebGPU emitter
+//                                        words them (wgsl.rs:268-540) instead of its WebGL2 emitter
 //   game compare A B [--threshold T]     two frames (.ppm or .png written by this tool): share of pixels whose
 //                                        channels all differ by <= T (the measure of snapshot.rs:240-258,
 //                                        default T = 2), max |difference| and PSNR; exit 1 when not identical
@@ -48,7 +50,7 @@ int usage()
             "usage: game check FILE...\n"
             "       game render FILE --hip [--size WxH] [--frames N] [--fps F] [--batch B] [--device D]\n"
             "                   [--cinematic I] [--out PREFIX] [--particles N --steps S]\n"
-            "                   [--png]\n"
+            "                   [--png] [--semantics glsl|wgsl]\n"
             "       game compare A B [--threshold T]\n"
             "       game ir FILE | game kernel FILE [--size WxH] | game builtins\n");
     return 2;
@@ -56,7 +58,7 @@ int usage()
 
 struct Args {
     std::vector<std::string> files;
-    bool hip = false, png = false;
+    bool hip = false, png = false, wgsl = false;
     int threshold = 2;
     uint32_t w = 1920, h = 1080, frames = 60, batch = 16, cinematic = 0, particles = 0, steps = 1;
     double fps = 60.0;
@@ -74,6 +76,12 @@ bool parse_args(int argc, char** argv, int first, Args& a)
         };
         if (s == "--hip") a.hip = true;
         else if (s == "--png") a.png = true;
+        else if (s == "--semantics") {
+            const char* v = value("--semantics");
+            if (!v) return false;
+            if (!strcmp(v, "wgsl")) a.wgsl = true;
+            else if (strcmp(v, "glsl")) { fprintf(stderr, "game: --semantics wants glsl or wgsl\n"); return false; }
+        }
         else if (s == "--threshold") { const char* v = value("--threshold"); if (!v) return false; a.threshold = atoi(v); }
         else if (s == "--size") {
             const char* v = value("--size");
@@ -298,7 +306,7 @@ int cmd_render(const Args& a)
     do {
         if (a.cinematic >= game_program_cinematic_count(prog)) { fprintf(stderr, "game render: no cinematic %u\n", a.cinematic); break; }
         const game_ir* ir = game_program_ir(prog, a.cinematic);
-        if (game_hip_create(ir, a.w, a.h, a.device, &ctx) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
+        if (game_hip_create_ex(ir, a.w, a.h, a.device, a.wgsl ? GAME_HIP_SEMANTICS_WGSL : 0u, &ctx) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
         if (a.particles) {
             if (game_hip_particles_seed(ctx, a.particles, 0x9E3779B97F4A7C15ull) != GAME_OK ||
                 game_hip_particles_step(ctx, (float)(1.0 / a.fps), a.steps, 0, a.particles) != GAME_OK || game_hip_sync(ctx) != GAME_OK) {

@@ -51,11 +51,26 @@ const float PALETTES[8][12] = {   // glsl.rs:424-434
     {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 1.0f, 1.0f, 1.0f, 0.00f, 0.10f, 0.20f},
 };
 
-std::string stage_call(const IrStage& st)
+// Builtins the WebGPU emitter words differently (wgsl.rs:268-540); they have a gw_* device function.
+bool has_wgsl_variant(uint16_t b)
+{
+    switch (b) {
+    case B_STAR: case B_POLYGON: case B_SIMPLEX: case B_VORONOI: case B_CONCENTRIC_WAVES: case B_THRESHOLD: case B_VIGNETTE:
+    case B_CHROMATIC: case B_TONEMAP: case B_SCANLINES: case B_GLITCH: case B_MIRROR: case B_REPEAT: case B_CURL_NOISE:
+    case B_DISPLACE: case B_SPECTRUM:
+        return true;
+    default:
+        return false;
+    }
+}
+
+std::string stage_call(const IrStage& st, bool wgsl)
 {
     auto A = [&](int i) { return arg_expr(st.args[i]); };
     auto call = [&](const char* fn, int n) {
-        std::string c = std::string(fn) + "(s";
+        std::string name(fn);
+        if (wgsl && has_wgsl_variant(st.builtin)) name[1] = 'w';   // gb_xxx -> gw_xxx
+        std::string c = name + "(s";
         for (int i = 0; i < n; ++i) c += ", " + A(i);
         return c + ");";
     };
@@ -173,7 +188,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
         k += "    {   // layer " + std::to_string(li) + "\n";
         k += "        s.px = s.uvx * aspect; s.py = s.uvy; s.sdf = 0.0f; s.r = s.g = s.b = s.a = 0.0f;\n";
         for (uint32_t si = 0; si < L.stage_count; ++si)
-            k += "        " + stage_call(ir.stages[L.stage_begin + si]) + "\n";
+            k += "        " + stage_call(ir.stages[L.stage_begin + si], shape.wgsl) + "\n";
         if (L.has_memory) k += "        gb_memory_mix(s, prev, " + float_literal(L.decay) + ");\n";
         if (ir.multi_layer) {
             k += "        fr = fr + s.r - fr * s.r; fg = fg + s.g - fg * s.g; fb = fb + s.b - fb * s.b; fa = 1.0f;\n";

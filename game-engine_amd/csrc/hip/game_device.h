@@ -655,6 +655,190 @@ GD void gb_spectrum(GdPix& s, float bass, float mid, float treble)              
     s.a = 1.0f;
 }
 
+// ── WGSL-semantics variants (game-compiler/src/codegen/wgsl.rs:268-540) ─────────────────────────
+// The reference's WebGPU emitter words sixteen builtins differently from its WebGL2 emitter (another
+// star / polygon fold, gradient simplex, arithmetic-hash voronoi, ACES tonemap, cartesian repeat,
+// radial spectrum, ...). A context created with GAME_HIP_SEMANTICS_WGSL calls these instead; every
+// other builtin is shared. The same evaluation rules apply (one rounding per operator, the listed
+// contraction points, reciprocal-multiply for quotients by a stage argument or constant).
+GD float gw_rem(float x, float y) { return x - y * __builtin_truncf(x * gd_rcp(y)); }   // WGSL `%` on f32
+GD float gw_step(float edge, float x) { return edge <= x ? 1.0f : 0.0f; }
+GD float gw_fold(float angle, float seg) { return gw_rem(gw_rem(angle, seg) + seg, seg); }   // wgsl.rs:291
+GD void gw_star(GdPix& s, float points, float radius, float inner)                                      // wgsl.rs:282-294
+{
+    float angle = gd_atan2(s.py, s.px);
+    float r = gd_length2(s.px, s.py);
+    float seg = 6.28318f * gd_rcp(points);
+    float a = gd_abs(gw_fold(angle, seg) - seg * 0.5f);
+    float sa, ca;
+    gd_sincos(a, sa, ca);
+    s.sdf = r * ca - radius + (r * sa - inner) * 0.5f;
+}
+GD void gw_polygon(GdPix& s, float sides, float radius)                                                 // wgsl.rs:301-312
+{
+    float a = gd_atan2(s.py, s.px);
+    float r = gd_length2(s.px, s.py);
+    float seg = 6.28318f * gd_rcp(sides);
+    float ha = gd_abs(gw_fold(a, seg) - seg * 0.5f);
+    s.sdf = r * gd_cos(ha) - radius;
+}
+// hash2v (wgsl.rs:206-209) of a lattice point: -1 + 2 * {the voronoi feature point of the WebGL2 path},
+// so it reads the same table when the point is inside it.
+GD void gw_hash2v(float x, float y, const float* __restrict__ vlut, float& hx, float& hy)
+{
+    float fx, fy;
+    if (vlut != nullptr && gd_abs(x) <= 512.0f && gd_abs(y) <= 512.0f) {
+        gd_u32 u = gd_bits(x + 12583424.0f) & 0x7ffu, v = gd_bits(y + 12583424.0f) & 0x7ffu;
+        gd_f32x2 e = *(const gd_f32x2*)((const char*)vlut + ((v << 14) | (u << 3)));
+        fx = e[0]; fy = e[1];
+    } else {
+        fx = gd_fract(gd_sin(x * 127.1f + y * 311.7f) * 43758.5453f);
+        fy = gd_fract(gd_sin(x * 269.5f + y * 183.3f) * 43758.5453f);
+    }
+    hx = -1.0f + 2.0f * fx; hy = -1.0f + 2.0f * fy;
+}
+GD float gw_simplex2(float px, float py, const float* __restrict__ vlut)                               // wgsl.rs:211-222
+{
+    const float K1 = 0.366025404f, K2 = 0.211324865f;
+    float sk = (px + py) * K1;
+    float ix = gd_floor(px + sk), iy = gd_floor(py + sk);
+    float t = (ix + iy) * K2;
+    float ax = px - ix + t, ay = py - iy + t;
+    float ox = gw_step(ay, ax), oy = gw_step(ax, ay);
+    float bx = ax - ox + K2, by = ay - oy + K2;
+    float cx = ax - 1.0f + 2.0f * K2, cy = ay - 1.0f + 2.0f * K2;
+    float h0 = gd_max(0.5f - (ax * ax + ay * ay), 0.0f);
+    float h1 = gd_max(0.5f - (bx * bx + by * by), 0.0f);
+    float h2 = gd_max(0.5f - (cx * cx + cy * cy), 0.0f);
+    float g0x, g0y, g1x, g1y, g2x, g2y;
+    gw_hash2v(ix, iy, vlut, g0x, g0y);
+    gw_hash2v(ix + ox, iy + oy, vlut, g1x, g1y);
+    gw_hash2v(ix + 1.0f, iy + 1.0f, vlut, g2x, g2y);
+    float n0 = h0 * h0 * h0 * h0 * (ax * g0x + ay * g0y);
+    float n1 = h1 * h1 * h1 * h1 * (bx * g1x + by * g1y);
+    float n2 = h2 * h2 * h2 * h2 * (cx * g2x + cy * g2y);
+    return n0 * 70.0f + n1 * 70.0f + n2 * 70.0f;
+}
+GD void gw_simplex(GdPix& s, float scale) { s.sdf = gw_simplex2(s.px * scale, s.py * scale, s.vlut); }   // wgsl.rs:320-323
+GD float gw_voronoi2(float px, float py, float scale, const float* __restrict__ lut)                    // wgsl.rs:187-201
+{
+    float spx = px * scale, spy = py * scale;
+    float ipx = gd_floor(spx), ipy = gd_floor(spy);
+    float fpx = gd_fract(spx), fpy = gd_fract(spy);
+    const bool table = lut != nullptr && gd_abs(ipx) <= 510.0f && gd_abs(ipy) <= 510.0f;
+    float h[3][3];
+    if (table) {
+        // rows ipy - 1 and ipy of the pair table hold {h(y-1), h(y)} and {h(y), h(y+1)} for columns ipx - 1 .. ipx + 1
+        gd_u32 u = gd_bits(ipx + 12583423.0f) & 0x7ffu, v = gd_bits(ipy + 12583423.0f) & 0x7ffu;
+        const char* base = (const char*)lut + ((v << 14) | (u << 3));
+        gd_f32x4_a8 lo01 = *(const gd_f32x4_a8*)base;
+        gd_f32x2 lo2 = *(const gd_f32x2*)(base + 16);
+        gd_f32x4_a8 hi01 = *(const gd_f32x4_a8*)(base + GD_LUT_STRIDE * 8u);
+        gd_f32x2 hi2 = *(const gd_f32x2*)(base + GD_LUT_STRIDE * 8u + 16);
+        h[0][0] = lo01[0]; h[1][0] = lo01[1]; h[0][1] = lo01[2]; h[1][1] = lo01[3]; h[0][2] = lo2[0]; h[1][2] = lo2[1];
+        h[2][0] = hi01[1]; h[2][1] = hi01[3]; h[2][2] = hi2[1];
+    } else {
+#pragma unroll
+        for (int y = 0; y < 3; y++)
+#pragma unroll
+            for (int x = 0; x < 3; x++) h[y][x] = gd_hash2(ipx + (float)(x - 1), ipy + (float)(y - 1));
+    }
+    float d = 1.0f;
+#pragma unroll
+    for (int y = -1; y <= 1; y++) {
+#pragma unroll
+        for (int x = -1; x <= 1; x++) {
+            float nx = (float)x, ny = (float)y;
+            float pv = h[y + 1][x + 1];
+            float ptx = nx + pv - fpx, pty = ny + gd_fract(pv * 17.0f) - fpy;
+            d = gd_min(d, ptx * ptx + pty * pty);
+        }
+    }
+    return gd_sqrt(d);
+}
+GD void gw_voronoi(GdPix& s, float scale) { s.sdf = gw_voronoi2(s.px, s.py, scale, s.lut); }            // wgsl.rs:324-327
+GD void gw_concentric_waves(GdPix& s, float amplitude, float width, float frequency)                    // wgsl.rs:328-334
+{
+    float len = gd_length2(s.px, s.py);
+    float r = len * frequency;
+    s.sdf = gd_sin(r - s.time * 2.0f) * amplitude * gd_exp(-len * width);
+}
+GD void gw_threshold(GdPix& s, float cutoff) { s.sdf = gw_step(cutoff, s.sdf); }                        // wgsl.rs:501-504
+GD void gw_vignette(GdPix& s, float strength, float radius)                                             // wgsl.rs:392-398
+{
+    float d = gd_length2(s.uvx, s.uvy);
+    float vig = gd_smoothstep(radius + 0.3f, radius - 0.2f, d);
+    float f = gd_mix(1.0f, vig, strength);
+    s.r = s.r * f; s.g = s.g * f; s.b = s.b * f;
+}
+GD void gw_chromatic(GdPix& s, float offset)                                                            // wgsl.rs:399-408
+{
+    float d = gd_length2(s.uvx, s.uvy) * offset;
+    s.r = s.r + d * 0.5f;
+    s.b = s.b - d * 0.5f;
+}
+GD float gw_aces(float x)                                                                               // wgsl.rs:409-419
+{
+    return gd_clamp((x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f), 0.0f, 1.0f);
+}
+GD void gw_tonemap(GdPix& s, float exposure)
+{
+    s.r = gw_aces(s.r * exposure); s.g = gw_aces(s.g * exposure); s.b = gw_aces(s.b * exposure);
+}
+GD void gw_scanlines(GdPix& s, float frequency, float intensity)                                        // wgsl.rs:420-425
+{
+    float scan = gd_sin(s.uvy * frequency * 3.14159f) * 0.5f + 0.5f;
+    float f = 1.0f - intensity * (1.0f - scan);
+    s.r = s.r * f; s.g = s.g * f; s.b = s.b * f;
+}
+GD void gw_glitch(GdPix& s, float intensity)                                                            // wgsl.rs:431-437
+{
+    float gt = gd_floor(s.time * 8.0f);
+    float off = (gd_fract(gd_sin(gt * 12.9898f) * 43758.5453f) - 0.5f) * intensity * 0.1f;
+    float block = gw_step(0.9f - intensity * 0.3f, gd_fract(gd_sin(s.uvy * 20.0f * 12.9898f + gt * 78.233f) * 43758.5453f));
+    s.r = gd_mix(s.r, s.r + off, block);
+    s.g = gd_mix(s.g, s.g - off * 0.5f, block);
+    s.b = gd_mix(s.b, s.b, block);
+}
+GD void gw_mirror(GdPix& s, float axis)                                                                 // wgsl.rs:464-468
+{
+    if (axis > 0.5f) s.py = gd_abs(s.py); else s.px = gd_abs(s.px);
+}
+GD void gw_repeat(GdPix& s, float count)                                                                // wgsl.rs:469-475
+{
+    float rep = 2.0f * gd_rcp(count);
+    s.px = gw_fold(s.px, rep) - rep * 0.5f;
+    s.py = gw_fold(s.py, rep) - rep * 0.5f;
+}
+GD void gw_curl_noise(GdPix& s, float frequency, float amplitude)                                       // wgsl.rs:481-488
+{
+    const float eps = 0.01f;
+    float a, b, c, d;
+    gd_noise2_pair_lut((s.px + eps) * frequency, (s.py + 0.0f) * frequency, (s.px - eps) * frequency, (s.py - 0.0f) * frequency, s.lut, a, b);
+    gd_noise2_pair_lut((s.px + 0.0f) * frequency, (s.py + eps) * frequency, (s.px - 0.0f) * frequency, (s.py - eps) * frequency, s.lut, c, d);
+    float cnx = a - b, cny = c - d;
+    const float inv = gd_rcp(2.0f * eps);
+    s.px = s.px + cny * amplitude * inv;
+    s.py = s.py + -cnx * amplitude * inv;
+}
+GD void gw_displace(GdPix& s, float strength)                                                           // wgsl.rs:489-492
+{
+    float n0, n1;
+    gd_noise2_pair_lut(s.px * 3.0f, s.py * 3.0f, s.px * 3.0f + 5.0f, s.py * 3.0f + 3.0f, s.lut, n0, n1);
+    s.px = s.px + n0 * strength; s.py = s.py + n1 * strength;
+}
+GD void gw_spectrum(GdPix& s, float bass, float mid, float treble)                                      // wgsl.rs:520-534
+{
+    float d = gd_length2(s.px, s.py);
+    float sb = gd_smoothstep(0.35f, 0.15f, d) * bass;
+    float sm = gd_smoothstep(0.55f, 0.35f, d) * gd_smoothstep(0.15f, 0.35f, d) * mid;
+    float st = gd_smoothstep(0.75f, 0.55f, d) * gd_smoothstep(0.35f, 0.55f, d) * treble;
+    s.r = sb * 1.0f + sm * 0.1f + st * 0.2f;
+    s.g = sb * 0.2f + sm * 1.0f + st * 0.3f;
+    s.b = sb * 0.1f + sm * 0.3f + st * 1.0f;
+    s.a = 1.0f;
+}
+
 // b / 255 for b in 0..255, correctly rounded, without the division sequence: q = b * RN(1/255) is
 // within one ulp, the residual b - 255 q is exact in one fma, and the corrected q is the correctly
 // rounded quotient for every one of the 256 inputs (checked exhaustively by the tests).

@@ -147,9 +147,10 @@ bool uses_lattice_noise(const Ir& ir)
 // frame store (and the previous-frame load): four pixels per lane turn those into 16-byte accesses.
 // Noise-heavy cinematics are bound by VALU issue and keep one pixel per lane (fewest registers,
 // no unrolled copies of a long body). Rows stay 16-byte aligned only when the width is a multiple of 4.
-KernelShape shape_for(const Ir& ir, uint32_t width)
+KernelShape shape_for(const Ir& ir, uint32_t width, uint32_t flags = 0)
 {
     KernelShape s;
+    s.wgsl = (flags & GAME_HIP_SEMANTICS_WGSL) != 0;
     bool heavy = false;
     for (const IrStage& st : ir.stages)
         switch (st.builtin) {
@@ -299,11 +300,13 @@ int game_hip_device_count(int* count)
     return GAME_OK;
 }
 
-int game_hip_compile_only(const game_ir* ir, size_t* code_bytes)
+int game_hip_compile_only(const game_ir* ir, size_t* code_bytes) { return game_hip_compile_only_ex(ir, 0, code_bytes); }
+
+int game_hip_compile_only_ex(const game_ir* ir, uint32_t flags, size_t* code_bytes)
 {
     if (!ir) return set_error(GAME_E_ARGUMENT, "game_hip_compile_only: null ir");
     std::vector<char> code;
-    std::string src = generate_frame_kernel(*ir->ir, shape_for(*ir->ir, 3840u));
+    std::string src = generate_frame_kernel(*ir->ir, shape_for(*ir->ir, 3840u, flags));
     int rc = compile_hip(src, "game_frame.hip", code);
     if (rc) return rc;
     size_t total = code.size();
@@ -345,7 +348,13 @@ int game_hip_dump_code(const game_ir* ir, const char* path_prefix)
 
 int game_hip_create(const game_ir* ir, uint32_t width, uint32_t height, int device, game_hip_ctx** out)
 {
+    return game_hip_create_ex(ir, width, height, device, 0, out);
+}
+
+int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int device, uint32_t flags, game_hip_ctx** out)
+{
     if (!ir || !out) return set_error(GAME_E_ARGUMENT, "game_hip_create: null argument");
+    if (flags & ~(uint32_t)GAME_HIP_SEMANTICS_WGSL) return set_error(GAME_E_ARGUMENT, "game_hip_create_ex: unknown flag");
     *out = nullptr;
     if (width == 0 || height == 0 || width > 65536 || height > 65535)
         return set_error(GAME_E_ARGUMENT, "game_hip_create: width must be in 1..65536 and height in 1..65535");
@@ -360,7 +369,7 @@ int game_hip_create(const game_ir* ir, uint32_t width, uint32_t height, int devi
     c->ir = *ir->ir;
     c->device = device;
     c->w = width; c->h = height;
-    c->shape = shape_for(c->ir, c->w);
+    c->shape = shape_for(c->ir, c->w, flags);
     c->row_floats = BU_COUNT + (uint32_t)c->ir.uniforms.size();
     c->ustride = c->row_floats + 2;
     c->source = generate_frame_kernel(c->ir, c->shape);
@@ -379,7 +388,14 @@ int game_hip_create(const game_ir* ir, uint32_t width, uint32_t height, int devi
         rc = lut_for_current_device(0, &c->lut);
         if (rc) { game_hip_destroy(c); return rc; }
     }
-    if (uses_builtin(c->ir, B_VORONOI) && !getenv("GAME_HIP_NO_LUT")) {
+    // the feature-point table serves voronoi in the WebGL2 wording and the simplex gradients in the WebGPU wording;
+    // the WebGPU voronoi hashes with hash2 and reads the lattice table
+    const bool wgsl = c->shape.wgsl;
+    if (wgsl && uses_builtin(c->ir, B_VORONOI) && !c->lut && !getenv("GAME_HIP_NO_LUT")) {
+        rc = lut_for_current_device(0, &c->lut);
+        if (rc) { game_hip_destroy(c); return rc; }
+    }
+    if (uses_builtin(c->ir, wgsl ? B_SIMPLEX : B_VORONOI) && !getenv("GAME_HIP_NO_LUT")) {
         rc = lut_for_current_device(1, &c->vlut);
         if (rc) { game_hip_destroy(c); return rc; }
     }

@@ -122,6 +122,13 @@ enum {
  * hand-written gfx950 device functions and compiles it with hiprtc. `device` is a HIP ordinal. */
 int game_hip_device_count(int* count);
 int game_hip_create(const game_ir* ir, uint32_t width, uint32_t height, int device, game_hip_ctx** out);
+/* Same with flags. GAME_HIP_SEMANTICS_WGSL: the sixteen builtins that the reference's WebGPU emitter
+ * (game-compiler/src/codegen/wgsl.rs:268-540) words differently from its WebGL2 emitter (star, polygon,
+ * simplex, voronoi, concentric_waves, threshold, vignette, chromatic, tonemap, scanlines, glitch, mirror,
+ * repeat, curl_noise, displace, spectrum) follow the WebGPU text; flags = 0 is game_hip_create. */
+enum { GAME_HIP_SEMANTICS_WGSL = 1u };
+int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int device, uint32_t flags,
+                       game_hip_ctx** out);
 void game_hip_destroy(game_hip_ctx* ctx);
 
 /* game_hip_render replaces GameRendererGL.render (runtime/helpers.rs:214-235) for `nframes`
@@ -150,6 +157,7 @@ int game_hip_last_kernel_ms(game_hip_ctx* ctx, float* ms, uint32_t* launches);
 const char* game_hip_kernel_source(const game_hip_ctx* ctx);
 /* Compile the generated kernel for gfx950 without touching a device (build-time check). */
 int game_hip_compile_only(const game_ir* ir, size_t* code_bytes);
+int game_hip_compile_only_ex(const game_ir* ir, uint32_t flags, size_t* code_bytes);
 /* Same, and writes <prefix>_frame.hip / <prefix>_frame.co (and _gravity.*): the generated source
  * and the gfx950 code object, for disassembly and instruction-mix studies. */
 int game_hip_dump_code(const game_ir* ir, const char* path_prefix);

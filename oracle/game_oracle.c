@@ -190,6 +190,7 @@ static const float PALETTES[8][12] = {
 
 /* ── one pixel ─────────────────────────────────────────────────────────────────────────── */
 typedef struct {
+    int wgsl;        /* builtins as worded by the WebGPU emitter (wgsl.rs:268-540) where they differ */
     float time;      /* fract(u_time / 120) * 120 */
     float aspect;    /* u_resolution.x / u_resolution.y */
     const float* row;/* this frame's uniform row: 10 built-ins then user uniforms */
@@ -206,6 +207,165 @@ static inline uint32_t pack_unorm8(float c)   /* framebuffer write: round(clamp(
 {
     float t = gm_min(gm_max(c, 0.0f), 1.0f);
     return (uint32_t)fmaf(t, 255.0f, 0.5f);
+}
+
+/* ── WGSL-semantics variants (game-compiler/src/codegen/wgsl.rs) ───────────────────────── */
+static inline float w_rem(float x, float y) { return x - y * truncf(x * gm_rcp(y)); }   /* WGSL `%` on f32 */
+static inline float w_step(float edge, float x) { return edge <= x ? 1.0f : 0.0f; }
+static inline float w_fold(float a, float seg) { return w_rem(w_rem(a, seg) + seg, seg); }   /* wgsl.rs:291 */
+
+static void w_hash2v(float x, float y, float* hx, float* hy)   /* wgsl.rs:206-209 */
+{
+    float fx = gm_fract(gm_sin(x * 127.1f + y * 311.7f) * 43758.5453f);
+    float fy = gm_fract(gm_sin(x * 269.5f + y * 183.3f) * 43758.5453f);
+    *hx = -1.0f + 2.0f * fx; *hy = -1.0f + 2.0f * fy;
+}
+
+static float w_simplex2(float px, float py)   /* wgsl.rs:211-222 */
+{
+    const float K1 = 0.366025404f, K2 = 0.211324865f;
+    float sk = (px + py) * K1;
+    float ix = gm_floor(px + sk), iy = gm_floor(py + sk);
+    float t = (ix + iy) * K2;
+    float ax = px - ix + t, ay = py - iy + t;
+    float ox = w_step(ay, ax), oy = w_step(ax, ay);
+    float bx = ax - ox + K2, by = ay - oy + K2;
+    float cx = ax - 1.0f + 2.0f * K2, cy = ay - 1.0f + 2.0f * K2;
+    float h0 = gm_max(0.5f - (ax * ax + ay * ay), 0.0f);
+    float h1 = gm_max(0.5f - (bx * bx + by * by), 0.0f);
+    float h2 = gm_max(0.5f - (cx * cx + cy * cy), 0.0f);
+    float g0x, g0y, g1x, g1y, g2x, g2y;
+    w_hash2v(ix, iy, &g0x, &g0y);
+    w_hash2v(ix + ox, iy + oy, &g1x, &g1y);
+    w_hash2v(ix + 1.0f, iy + 1.0f, &g2x, &g2y);
+    float n0 = h0 * h0 * h0 * h0 * (ax * g0x + ay * g0y);
+    float n1 = h1 * h1 * h1 * h1 * (bx * g1x + by * g1y);
+    float n2 = h2 * h2 * h2 * h2 * (cx * g2x + cy * g2y);
+    return n0 * 70.0f + n1 * 70.0f + n2 * 70.0f;
+}
+
+static float w_voronoi2(float px, float py, float scale)   /* wgsl.rs:187-201 */
+{
+    float spx = px * scale, spy = py * scale;
+    float ipx = gm_floor(spx), ipy = gm_floor(spy);
+    float fpx = gm_fract(spx), fpy = gm_fract(spy);
+    float d = 1.0f;
+    for (int y = -1; y <= 1; y++) {
+        for (int x = -1; x <= 1; x++) {
+            float nx = (float)x, ny = (float)y;
+            float pv = hash2(ipx + nx, ipy + ny);
+            float ptx = nx + pv - fpx, pty = ny + gm_fract(pv * 17.0f) - fpy;
+            d = gm_min(d, ptx * ptx + pty * pty);
+        }
+    }
+    return sqrtf(d);
+}
+
+static inline float w_aces(float x)   /* wgsl.rs:409-419 */
+{
+    return gm_clamp((x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f), 0.0f, 1.0f);
+}
+
+typedef struct { float px, py, sdf, cr, cg, cb, ca; } pix_state;
+
+/* Applies stage S in the WebGPU wording when that differs from the WebGL2 one; returns 0 when the
+ * builtin is shared and the caller's switch must run. */
+static int wgsl_stage(uint32_t builtin, pix_state* s, float a0, float a1, float a2, float uvx, float uvy, float time)
+{
+    switch (builtin) {
+    case B_STAR: {                                                                                 /* wgsl.rs:282-294 */
+        float angle = gm_atan2(s->py, s->px);
+        float r = gm_length2(s->px, s->py);
+        float seg = 6.28318f * gm_rcp(a0);
+        float a = gm_abs(w_fold(angle, seg) - seg * 0.5f);
+        s->sdf = r * gm_cos(a) - a1 + (r * gm_sin(a) - a2) * 0.5f;
+        return 1;
+    }
+    case B_POLYGON: {                                                                              /* wgsl.rs:301-312 */
+        float a = gm_atan2(s->py, s->px);
+        float r = gm_length2(s->px, s->py);
+        float seg = 6.28318f * gm_rcp(a0);
+        float ha = gm_abs(w_fold(a, seg) - seg * 0.5f);
+        s->sdf = r * gm_cos(ha) - a1;
+        return 1;
+    }
+    case B_SIMPLEX: s->sdf = w_simplex2(s->px * a0, s->py * a0); return 1;                         /* wgsl.rs:320-323 */
+    case B_VORONOI: s->sdf = w_voronoi2(s->px, s->py, a0); return 1;                               /* wgsl.rs:324-327 */
+    case B_CONCENTRIC_WAVES: {                                                                     /* wgsl.rs:328-334 */
+        float len = gm_length2(s->px, s->py);
+        float r = len * a2;
+        s->sdf = gm_sin(r - time * 2.0f) * a0 * gm_exp(-len * a1);
+        return 1;
+    }
+    case B_THRESHOLD: s->sdf = w_step(a0, s->sdf); return 1;                                       /* wgsl.rs:501-504 */
+    case B_VIGNETTE: {                                                                             /* wgsl.rs:392-398 */
+        float d = gm_length2(uvx, uvy);
+        float vig = gm_smoothstep(a1 + 0.3f, a1 - 0.2f, d);
+        float f = gm_mix(1.0f, vig, a0);
+        s->cr = s->cr * f; s->cg = s->cg * f; s->cb = s->cb * f;
+        return 1;
+    }
+    case B_CHROMATIC: {                                                                            /* wgsl.rs:399-408 */
+        float d = gm_length2(uvx, uvy) * a0;
+        s->cr = s->cr + d * 0.5f;
+        s->cb = s->cb - d * 0.5f;
+        return 1;
+    }
+    case B_TONEMAP: s->cr = w_aces(s->cr * a0); s->cg = w_aces(s->cg * a0); s->cb = w_aces(s->cb * a0); return 1;
+    case B_SCANLINES: {                                                                            /* wgsl.rs:420-425 */
+        float scan = gm_sin(uvy * a0 * 3.14159f) * 0.5f + 0.5f;
+        float f = 1.0f - a1 * (1.0f - scan);
+        s->cr = s->cr * f; s->cg = s->cg * f; s->cb = s->cb * f;
+        return 1;
+    }
+    case B_GLITCH: {                                                                               /* wgsl.rs:431-437 */
+        float gt = gm_floor(time * 8.0f);
+        float off = (gm_fract(gm_sin(gt * 12.9898f) * 43758.5453f) - 0.5f) * a0 * 0.1f;
+        float block = w_step(0.9f - a0 * 0.3f, gm_fract(gm_sin(uvy * 20.0f * 12.9898f + gt * 78.233f) * 43758.5453f));
+        s->cr = gm_mix(s->cr, s->cr + off, block);
+        s->cg = gm_mix(s->cg, s->cg - off * 0.5f, block);
+        s->cb = gm_mix(s->cb, s->cb, block);
+        return 1;
+    }
+    case B_MIRROR:                                                                                 /* wgsl.rs:464-468 */
+        if (a0 > 0.5f) s->py = gm_abs(s->py); else s->px = gm_abs(s->px);
+        return 1;
+    case B_REPEAT: {                                                                               /* wgsl.rs:469-475 */
+        float rep = 2.0f * gm_rcp(a0);
+        s->px = w_fold(s->px, rep) - rep * 0.5f;
+        s->py = w_fold(s->py, rep) - rep * 0.5f;
+        return 1;
+    }
+    case B_CURL_NOISE: {                                                                           /* wgsl.rs:481-488 */
+        const float eps = 0.01f;
+        float a = noise2((s->px + eps) * a0, (s->py + 0.0f) * a0), b = noise2((s->px - eps) * a0, (s->py - 0.0f) * a0);
+        float c = noise2((s->px + 0.0f) * a0, (s->py + eps) * a0), d = noise2((s->px - 0.0f) * a0, (s->py - eps) * a0);
+        float cnx = a - b, cny = c - d;
+        const float inv = gm_rcp(2.0f * eps);
+        s->px = s->px + cny * a1 * inv;
+        s->py = s->py + -cnx * a1 * inv;
+        return 1;
+    }
+    case B_DISPLACE: {                                                                             /* wgsl.rs:489-492 */
+        float n0 = noise2(s->px * 3.0f, s->py * 3.0f);
+        float n1 = noise2(s->px * 3.0f + 5.0f, s->py * 3.0f + 3.0f);
+        s->px = s->px + n0 * a0; s->py = s->py + n1 * a0;
+        return 1;
+    }
+    case B_SPECTRUM: {                                                                             /* wgsl.rs:520-534 */
+        float d = gm_length2(s->px, s->py);
+        float sb = gm_smoothstep(0.35f, 0.15f, d) * a0;
+        float sm = gm_smoothstep(0.55f, 0.35f, d) * gm_smoothstep(0.15f, 0.35f, d) * a1;
+        float st = gm_smoothstep(0.75f, 0.55f, d) * gm_smoothstep(0.35f, 0.55f, d) * a2;
+        s->cr = sb * 1.0f + sm * 0.1f + st * 0.2f;
+        s->cg = sb * 0.2f + sm * 1.0f + st * 0.3f;
+        s->cb = sb * 0.1f + sm * 0.3f + st * 1.0f;
+        s->ca = 1.0f;
+        return 1;
+    }
+    default:
+        return 0;
+    }
 }
 
 /* uvx, uvy: `uv` of glsl.rs:54. prev: previous frame's RGBA8 texel at this pixel. out: RGBA floats. */
@@ -226,6 +386,13 @@ static void shade_pixel(const ir_view* ir, const frame_consts* fc, float uvx, fl
             const ir_stage* S = &ir->stages[L->stage_begin + si];
             const float a0 = arg_value(&S->args[0], fc), a1 = arg_value(&S->args[1], fc);
             const float a2 = arg_value(&S->args[2], fc), a3 = arg_value(&S->args[3], fc);
+            if (fc->wgsl) {
+                pix_state st = {px, py, sdf, cr, cg, cb, ca};
+                if (wgsl_stage(S->builtin, &st, a0, a1, a2, uvx, uvy, time)) {
+                    px = st.px; py = st.py; sdf = st.sdf; cr = st.cr; cg = st.cg; cb = st.cb; ca = st.ca;
+                    continue;
+                }
+            }
             switch (S->builtin) {
             /* SDF generators */
             case B_CIRCLE: sdf = gm_length2(px, py) - a0; break;                                   /* :265-268, :96-100 */
@@ -470,12 +637,23 @@ static void* render_thread(void* p) { render_rows((const frame_job*)p); return N
 /* Renders image rows [row0, row0+rows) of one frame. uniforms: one row (10 + n_uniforms floats).
  * prev/out hold only the band, top row first, RGBA8 (R in the low byte). prev may be NULL (= all
  * zero). nthreads <= 1 renders on the calling thread. Returns 0, or -1 for a malformed blob. */
+int game_oracle_render_ex(const void* blob, size_t blob_len, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows,
+                          const float* uniforms, const uint8_t* prev_rgba8, uint8_t* out_rgba8, int nthreads, int semantics);
+
 int game_oracle_render(const void* blob, size_t blob_len, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows,
                        const float* uniforms, const uint8_t* prev_rgba8, uint8_t* out_rgba8, int nthreads)
+{
+    return game_oracle_render_ex(blob, blob_len, w, h, row0, rows, uniforms, prev_rgba8, out_rgba8, nthreads, 0);
+}
+
+/* semantics: 0 = the WebGL2 wording of every builtin (glsl.rs), 1 = the WebGPU wording where it differs (wgsl.rs). */
+int game_oracle_render_ex(const void* blob, size_t blob_len, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows,
+                          const float* uniforms, const uint8_t* prev_rgba8, uint8_t* out_rgba8, int nthreads, int semantics)
 {
     ir_view ir;
     if (ir_open(blob, blob_len, &ir) != 0 || !uniforms || !out_rgba8 || w == 0 || h == 0 || row0 + rows > h) return -1;
     frame_consts fc;
+    fc.wgsl = semantics == 1;
     fc.row = uniforms;
     fc.aspect = uniforms[BU_RES_X] / uniforms[BU_RES_Y];               /* glsl.rs:55 */
     fc.time = gm_fract(uniforms[BU_TIME] / 120.0f) * 120.0f;           /* glsl.rs:56 */

@@ -19,16 +19,18 @@ game = T.load_product()
 oracle = T.Oracle()
 
 
-def frame(src, w, h, t, audio):
+def frame(src, w, h, t, audio, semantics="glsl"):
     cin = game.compile(src).cinematics[0]
     rows = cin.uniform_rows([t], w, h, audio=audio)
-    return oracle.render(cin.blob, w, h, rows[0], threads=4)
+    return oracle.render(cin.blob, w, h, rows[0], threads=4, semantics=semantics)
 
 
 for name, (src, w, h, t, audio) in GOLDEN_CASES.items():
     np.save(os.path.join(HERE, name + ".npy"), frame(src, w, h, t, audio))
 np.savez_compressed(os.path.join(HERE, "gallery.npz"),
                     **{n: frame(s, 48, 27, 2.5, {"bass": 0.7, "mid": 0.2, "treble": 0.9}) for n, s in GALLERY.items()})
+np.savez_compressed(os.path.join(HERE, "gallery_wgsl.npz"),
+                    **{n: frame(s, 48, 27, 2.5, {"bass": 0.7, "mid": 0.2, "treble": 0.9}, "wgsl") for n, s in GALLERY.items()})
 src = 'cinematic "t" { gravity { rule: 0.01 / (dist * dist + 0.01) * sin(time * 3.0 + 1.0), damping: 0.98, bounds: wrap } layer s { circle() | glow() } }'
 cin = game.compile(src).cinematics[0]
 p, _ = oracle.gravity(cin.blob, oracle.seed_particles(257), 1 / 60, 5, threads=4)

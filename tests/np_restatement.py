@@ -184,3 +184,32 @@ def gravity_step(p, dt, damping, law, bounds, time):
         px = fract((px + F(1.0)) * F(0.5)) * F(2.0) - F(1.0)
         py = fract((py + F(1.0)) * F(0.5)) * F(2.0) - F(1.0)
     return np.stack([px, py, vx, vy], axis=1).astype(np.float32)
+
+
+def render_wgsl_post_chain(w, h):
+    """spectrum(0.9, 0.7, 0.5) | bloom(0.4, 2.0) | chromatic(0.6) | vignette(0.35, 0.8) | tonemap(1.2) in the
+    wording of the reference's WebGPU emitter (wgsl.rs:520-534, :381-386, :399-408, :392-398, :409-419)."""
+    uvx, uvy = pixel_grid(w, h)
+    aspect = F(w) / F(h)
+    px, py = uvx * aspect, uvy
+    d = np.sqrt(fma(px, px, py * py))
+    sb = smoothstep(0.35, 0.15, d) * F(0.9)
+    sm = smoothstep(0.55, 0.35, d) * smoothstep(0.15, 0.35, d) * F(0.7)
+    st = smoothstep(0.75, 0.55, d) * smoothstep(0.35, 0.55, d) * F(0.5)
+    r = sb * F(1.0) + sm * F(0.1) + st * F(0.2)
+    g = sb * F(0.2) + sm * F(1.0) + st * F(0.3)
+    b = sb * F(0.1) + sm * F(0.3) + st * F(1.0)
+    lum = r * F(0.299) + g * F(0.587) + b * F(0.114)
+    add = np.maximum(lum - F(0.4), F(0.0)) * F(2.0)
+    r, g, b = r + add, g + add, b + add
+    ln = np.sqrt(fma(uvx, uvx, uvy * uvy))
+    chr_d = ln * F(0.6)
+    r, b = r + chr_d * F(0.5), b - chr_d * F(0.5)
+    vig = smoothstep(F(0.8) + F(0.3), F(0.8) - F(0.2), ln)
+    f = mix(F(1.0), vig, F(0.35))
+    r, g, b = r * f, g * f, b * f
+
+    def aces(x):
+        x = x * F(1.2)
+        return clamp((x * (F(2.51) * x + F(0.03))) / (x * (F(2.43) * x + F(0.59)) + F(0.14)), 0.0, 1.0)
+    return pack(aces(r), aces(g), aces(b), 1.0)

@@ -84,3 +84,15 @@ def test_blob_header(game):
     assert (h["n_layers"], h["n_stages"], h["uses_memory"], h["multi_layer"]) == (1, 4, 1, 0)
     g = game.parse_blob(game.compile(C5_GRAVITY).cinematics[0].blob)
     assert g["gravity_present"] == 1 and g["damping"] == np.float32(0.995) and g["bounds"] == 0
+
+
+def test_wgsl_semantics_kernels_compile_and_call_the_variants(game):
+    """The WebGPU wording is a second set of device functions (gw_*) for the sixteen builtins that differ."""
+    from gallery import GALLERY
+    src = ('cinematic "w" { layer { fn: repeat(3.0) | polygon(6.0, 0.3) | threshold(0.0) | glow(1.0) | tonemap(1.2) | '
+           'scanlines(200.0, 0.3) | chromatic(0.4) | vignette(0.4, 0.7) | glitch(0.5) } }')
+    cin = game.compile(src).cinematics[0]
+    assert cin.compile_only(semantics="wgsl") > 0 and cin.compile_only() > 0
+    for name in ("noise_mix", "voronoi", "simplex"):
+        if name in GALLERY:
+            assert game.compile(GALLERY[name]).cinematics[0].compile_only(semantics="wgsl") > 0

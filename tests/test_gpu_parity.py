@@ -23,15 +23,15 @@ def psnr(a, b):
     return float("inf") if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
 
 
-def check(game, oracle, src, w, h, times, audio=None, user=None):
+def check(game, oracle, src, w, h, times, audio=None, user=None, semantics="glsl"):
     cin = game.compile(src).cinematics[0]
     rows = cin.uniform_rows(times, w, h, audio=audio, user=user)
-    r = cin.renderer(w, h)
+    r = cin.renderer(w, h, semantics=semantics)
     try:
         got = r.render(rows)
     finally:
         r.close()
-    want = oracle.render_sequence(cin.blob, w, h, rows, cin.uses_memory)
+    want = oracle.render_sequence(cin.blob, w, h, rows, cin.uses_memory, semantics=semantics)
     diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
     assert diff.max() <= 1 and psnr(got, want) >= 50.0       # the stated tolerance
     assert diff.max() == 0, f"{np.count_nonzero(diff.max(axis=-1))} pixels differ"   # and in fact exact
@@ -177,6 +177,23 @@ def test_memory_state_carries_across_calls_and_resets(game, oracle):
 @pytest.mark.parametrize("name", sorted(GALLERY))
 def test_gallery(game, oracle, name):
     check(game, oracle, GALLERY[name], 96, 54, [2.5, 60.0, 119.5], audio={"bass": 0.7, "mid": 0.2, "treble": 0.9, "beat": 3.0})
+
+
+# The same gallery in the reference's WebGPU wording of the builtins (wgsl.rs:268-540)
+@pytest.mark.parametrize("name", sorted(GALLERY))
+def test_gallery_wgsl_semantics(game, oracle, name):
+    check(game, oracle, GALLERY[name], 96, 54, [2.5, 60.0, 119.5], audio={"bass": 0.7, "mid": 0.2, "treble": 0.9, "beat": 3.0},
+          semantics="wgsl")
+
+
+def test_wgsl_semantics_tables_and_sizes(game, oracle):
+    """WebGPU voronoi reads the lattice-hash table and the WebGPU simplex the feature-point table: large scales push
+    cells outside both tables, so table and arithmetic paths meet inside one frame; ragged size, four pixels per lane."""
+    src = ('cinematic "w" { layer a { fn: voronoi(900.0) | glow(1.2) | tint(0.9, 0.5, 0.2) } '
+           'layer b { fn: simplex(700.0) | glow(0.8) | tint(0.2, 0.6, 0.9) } '
+           'layer c { fn: repeat(3.0) | star(5.0, 0.3, 0.15) | glow(2.0) | tonemap(1.4) | vignette(0.5, 0.6) } }')
+    check(game, oracle, src, 257, 67, [0.25, 7.0], semantics="wgsl")
+    check(game, oracle, C3_SHOWCASE, 128, 72, [0.5], audio={"bass": 0.8, "mid": 0.6, "treble": 0.4}, semantics="wgsl")
 
 
 def test_gallery_memory_sequence(game, oracle):

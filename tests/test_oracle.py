@@ -126,6 +126,29 @@ def test_c3_frame_matches_numpy_without_grain(game, oracle):
     assert got[8, 16, 0] == 0 and got[8, 16, 2] == 0
 
 
+def test_wgsl_semantics_post_chain_matches_numpy(game, oracle):
+    """The WebGPU wording of spectrum / chromatic / vignette / tonemap (radial bands, additive fringe, mixed
+    vignette, ACES) against an independent numpy statement of wgsl.rs."""
+    src = ('cinematic "w" { layer { fn: spectrum(0.9, 0.7, 0.5) | bloom(0.4, 2.0) | chromatic(0.6) | '
+           'vignette(0.35, 0.8) | tonemap(1.2) } }')
+    cin = game.compile(src).cinematics[0]
+    for w, h in ((96, 54), (33, 17)):
+        rows = cin.uniform_rows([0.0], w, h)
+        got = oracle.render(cin.blob, w, h, rows[0], semantics="wgsl")
+        assert np.array_equal(got, NP.render_wgsl_post_chain(w, h))
+        assert not np.array_equal(got, oracle.render(cin.blob, w, h, rows[0]))     # the two wordings differ
+
+
+def test_golden_builtin_gallery_wgsl(game, oracle):
+    from gallery import GALLERY
+    data = np.load(os.path.join(GOLDEN, "gallery_wgsl.npz"))
+    assert sorted(data.files) == sorted(GALLERY)
+    for name, src in GALLERY.items():
+        cin = game.compile(src).cinematics[0]
+        rows = cin.uniform_rows([2.5], 48, 27, audio={"bass": 0.7, "mid": 0.2, "treble": 0.9})
+        assert np.array_equal(oracle.render(cin.blob, 48, 27, rows[0], threads=4, semantics="wgsl"), data[name]), name
+
+
 def test_memory_feedback_recurrence(game, oracle):
     """Frame k = mix(current, RGBA8(frame k-1), 0.97) per channel, re-quantised every frame."""
     w, h, n = 48, 27, 8
