@@ -306,7 +306,7 @@ int cmd_render(const Args& a)
     do {
         if (a.cinematic >= game_program_cinematic_count(prog)) { fprintf(stderr, "game render: no cinematic %u\n", a.cinematic); break; }
         const game_ir* ir = game_program_ir(prog, a.cinematic);
-        if (game_hip_create_ex(ir, a.w, a.h, a.device, a.wgsl ? GAME_HIP_SEMANTICS_WGSL : 0u, &ctx) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
+        if (game_hip_create_ex(ir, a.w, a.h, a.device, a.wgsl ? (uint32_t)GAME_HIP_SEMANTICS_WGSL : 0u, &ctx) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
         if (a.particles) {
             if (game_hip_particles_seed(ctx, a.particles, 0x9E3779B97F4A7C15ull) != GAME_OK ||
                 game_hip_particles_step(ctx, (float)(1.0 / a.fps), a.steps, 0, a.particles) != GAME_OK || game_hip_sync(ctx) != GAME_OK) {
