@@ -58,6 +58,8 @@ def _load():
         "game_ir_has_gravity": (c.c_int, [vp]),
         "game_ir_frame_floats": (u32, [vp]),
         "game_ir_default_uniforms": (None, [vp, f32, u32, u32, vp]),
+        "game_ir_arc_count": (u32, [vp]),
+        "game_ir_arc_update": (None, [vp, c.c_double, vp]),
         "game_hip_device_count": (c.c_int, [c.POINTER(c.c_int)]),
         "game_hip_create": (c.c_int, [vp, u32, u32, c.c_int, c.POINTER(vp)]),
         "game_hip_create_ex": (c.c_int, [vp, u32, u32, c.c_int, u32, c.POINTER(vp)]),
@@ -144,8 +146,9 @@ class Cinematic:
     def frame_floats(self):
         return lib.game_ir_frame_floats(self._h)
 
-    def uniform_rows(self, times, w, h, audio=None, user=None):
-        """Frame uniform table: one row per entry of `times` (seconds), reference defaults elsewhere."""
+    def uniform_rows(self, times, w, h, audio=None, user=None, arcs=False):
+        """Frame uniform table: one row per entry of `times` (seconds), reference defaults elsewhere. arcs=True
+        applies the cinematic's arc timeline (runtime/arc.rs:110-122) to the user uniforms of every row, after `user`."""
         times = np.asarray(times, dtype=np.float32).reshape(-1)
         rows = np.zeros((len(times), self.frame_floats), dtype=np.float32)
         for k, t in enumerate(times):
@@ -158,7 +161,14 @@ class Cinematic:
             names = [n for n, _ in self.uniforms]
             for key, val in user.items():
                 rows[:, BU_COUNT + names.index(key)] = np.asarray(val, dtype=np.float32)
+        if arcs:
+            for k, t in enumerate(times):
+                lib.game_ir_arc_update(self._h, float(t), rows[k].ctypes.data)
         return rows
+
+    @property
+    def arc_count(self):
+        return lib.game_ir_arc_count(self._h)
 
     def compile_only(self, semantics="glsl"):
         """hiprtc-compiles the generated kernels for gfx950 without a device; returns code bytes."""

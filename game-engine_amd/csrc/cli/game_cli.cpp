@@ -9,7 +9,8 @@
 //                                        browser): renders N frames with u_time = k / F on the GPU; with
 //                                        --out writes PREFIX_00000.ppm ... (binary P6, RGB of the RGBA8 frame),
 //                                        or PREFIX_00000.png (8-bit RGBA, stored deflate blocks) with --png;
-//                                        --semantics wgsl renders the builtins as the reference's WebGPU emitter
+//                                        the cinematic's arc timeline (runtime/arc.rs) drives its parameters unless
+//                                        --no-arcs; --semantics wgsl renders the builtins as the reference's WebGPU emitter
 //                                        words them (wgsl.rs:268-540) instead of its WebGL2 emitter
 //   game compare A B [--threshold T]     two frames (.ppm or .png written by this tool): share of pixels whose
 //                                        channels all differ by <= T (the measure of snapshot.rs:240-258,
@@ -50,7 +51,7 @@ int usage()
             "usage: game check FILE...\n"
             "       game render FILE --hip [--size WxH] [--frames N] [--fps F] [--batch B] [--device D]\n"
             "                   [--cinematic I] [--out PREFIX] [--particles N --steps S]\n"
-            "                   [--png] [--semantics glsl|wgsl]\n"
+            "                   [--png] [--semantics glsl|wgsl] [--no-arcs]\n"
             "       game compare A B [--threshold T]\n"
             "       game ir FILE | game kernel FILE [--size WxH] | game builtins\n");
     return 2;
@@ -58,7 +59,7 @@ int usage()
 
 struct Args {
     std::vector<std::string> files;
-    bool hip = false, png = false, wgsl = false;
+    bool hip = false, png = false, wgsl = false, arcs = true;
     int threshold = 2;
     uint32_t w = 1920, h = 1080, frames = 60, batch = 16, cinematic = 0, particles = 0, steps = 1;
     double fps = 60.0;
@@ -76,6 +77,7 @@ bool parse_args(int argc, char** argv, int first, Args& a)
         };
         if (s == "--hip") a.hip = true;
         else if (s == "--png") a.png = true;
+        else if (s == "--no-arcs") a.arcs = false;
         else if (s == "--semantics") {
             const char* v = value("--semantics");
             if (!v) return false;
@@ -331,7 +333,11 @@ int cmd_render(const Args& a)
         bool ok = true;
         for (uint32_t done = 0; done < a.frames && ok; done += batch) {
             uint32_t n = a.frames - done < batch ? a.frames - done : batch;
-            for (uint32_t k = 0; k < n; ++k) game_ir_default_uniforms(ir, (float)((done + k) / a.fps), a.w, a.h, rows.data() + (size_t)k * nf);
+            for (uint32_t k = 0; k < n; ++k) {
+                float* row = rows.data() + (size_t)k * nf;
+                game_ir_default_uniforms(ir, (float)((done + k) / a.fps), a.w, a.h, row);
+                if (a.arcs) game_ir_arc_update(ir, (done + k) / a.fps, row);   // the cinematic's own timeline animates its parameters
+            }
             if (game_hip_render(ctx, rows.data(), n, host.empty() ? nullptr : host.data()) != GAME_OK) { ok = false; break; }
             float ms = 0; uint32_t launches = 0;
             game_hip_last_kernel_ms(ctx, &ms, &launches);

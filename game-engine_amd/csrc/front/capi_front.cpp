@@ -1,6 +1,7 @@
 // C ABI for the front end (include/game_hip.h, "front end" and "IR accessors" sections).
 #include "front.hpp"
 #include "capi_internal.hpp"
+#include <vector>
 #include <cstring>
 
 using namespace game;
@@ -123,6 +124,18 @@ void game_ir_default_uniforms(const game_ir* ir, float time_s, uint32_t w, uint3
     row[BU_RES_X] = (float)w;
     row[BU_RES_Y] = (float)h;
     for (size_t i = 0; i < ir->ir->uniforms.size(); ++i) row[BU_COUNT + i] = (float)ir->ir->uniforms[i].def;
+}
+
+uint32_t game_ir_arc_count(const game_ir* ir) { return ir ? (uint32_t)ir->ir->arcs.size() : 0; }
+
+void game_ir_arc_update(const game_ir* ir, double time_s, float* row)
+{
+    if (!ir || !row || ir->ir->arcs.empty()) return;
+    const size_t n = ir->ir->uniforms.size();
+    std::vector<double> params(n);
+    for (size_t i = 0; i < n; ++i) params[i] = (double)row[BU_COUNT + i];
+    arc_update(*ir->ir, time_s, params.data());
+    for (size_t i = 0; i < n; ++i) row[BU_COUNT + i] = (float)params[i];   // uploaded as Float32
 }
 
 }  // extern "C"

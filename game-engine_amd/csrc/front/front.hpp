@@ -231,6 +231,16 @@ struct IrGravity {
     std::vector<IrLawOp> law;     // postfix program over {dist, time}
     std::string law_text;         // as printed into WGSL by the reference
 };
+// One entry of the arc timeline (runtime/arc.rs:52-125): uniform `idx` moves from `from` to `to` over
+// [start, start + dur) seconds through `easing`; entries run back to back in source order. idx < 0: the
+// target names no uniform, or an endpoint is not a constant number (the emitted JS would skip or fail there).
+struct IrArc {
+    int idx = -1;
+    std::string target;
+    double from = 0.0, to = 0.0, start = 0.0, dur = 0.0;
+    std::string easing;
+};
+
 struct Ir {
     std::string name;
     bool multi_layer = false;     // cinematic.layers.len() > 1, params layers included (glsl.rs:66)
@@ -240,7 +250,14 @@ struct Ir {
     std::vector<UniformInfo> uniforms;
     IrGravity gravity;
     bool uses_memory = false;
+    std::vector<IrArc> arcs;
 };
+
+// arcUpdate(time, params) of runtime/arc.rs:110-122 in JS number (double) arithmetic: applies the timeline to
+// `params` (one value per uniform, in uniform order).
+void arc_update(const Ir& ir, double time, double* params);
+// JS-number value of a constant expression as expr.rs:147 compile_js would word it; false when it is not one.
+bool eval_js_const(const Expr& e, double& out);
 
 Ir lower_cinematic(const Cinematic& c);                  // after validate; never fails
 std::vector<uint8_t> ir_serialize(const Ir& ir);         // flat little-endian blob (layout: include/game_hip.h)

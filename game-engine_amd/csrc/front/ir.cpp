@@ -3,6 +3,8 @@
 // pasted for each argument (game-compiler/src/codegen/glsl.rs:261-531 reads its arguments through
 // stages.rs:25 `get_arg` with the parameter lists of builtins.rs:43-217).
 #include "front.hpp"
+#include <cmath>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -192,6 +194,27 @@ Ir lower_cinematic(const Cinematic& c)
     }
     if (!any_pipeline) ir.flags |= IRF_NO_OUTPUT;
 
+    // arc timeline (runtime/arc.rs:62-93): blocks and entries concatenate, the cursor advances by each duration
+    double cursor = 0.0;
+    for (const ArcBlock& blk : c.arcs) {
+        for (const ArcEntry& e : blk.entries) {
+            IrArc a;
+            a.target = e.target;
+            a.dur = e.dur.kind == DurKind::Seconds ? e.dur.v : e.dur.kind == DurKind::Millis ? e.dur.v / 1000.0 : (double)e.dur.bars * 2.0;
+            a.start = cursor;
+            a.easing = e.has_easing ? e.easing : "linear";
+            std::string dotted = e.target;
+            for (char& ch : dotted) if (ch == '.') ch = '_';
+            size_t dot = e.target.rfind('.');
+            std::string bare = dot == std::string::npos ? e.target : e.target.substr(dot + 1);
+            for (size_t i = 0; i < ir.uniforms.size() && a.idx < 0; ++i) if (ir.uniforms[i].name == dotted) a.idx = (int)i;
+            for (size_t i = 0; i < ir.uniforms.size() && a.idx < 0; ++i) if (ir.uniforms[i].name == bare) a.idx = (int)i;
+            if (!eval_js_const(e.from, a.from) || !eval_js_const(e.to, a.to)) a.idx = -1;
+            ir.arcs.push_back(std::move(a));
+            cursor += ir.arcs.back().dur;
+        }
+    }
+
     if (c.has_gravity) {
         ir.gravity.present = true;
         ir.gravity.damping_text = fmt_f64_display(c.gravity.damping);   // `{damping}` (gravity.rs:92-95)
@@ -201,6 +224,110 @@ Ir lower_cinematic(const Cinematic& c)
         lower_law(c.gravity.force_law, ir);
     }
     return ir;
+}
+
+// ── arcs ─────────────────────────────────────────────────────────────────
+bool eval_js_const(const Expr& e, double& out)
+{
+    auto truthy = [](double v) { return v != 0.0 && v == v; };
+    switch (e.kind) {
+    case Expr::Number: out = e.num; return true;
+    case Expr::Paren: return eval_js_const(e.kids[0], out);
+    case Expr::Neg: if (!eval_js_const(e.kids[0], out)) return false; out = -out; return true;
+    case Expr::Dur: out = e.dur.kind == DurKind::Seconds ? e.dur.v : e.dur.kind == DurKind::Millis ? e.dur.v / 1000.0 : (double)e.dur.bars * 2.0; return true;
+    case Expr::Ident:   // expr.rs:39-47 constants; `time`, colours (arrays) and free names are not numbers
+        if (e.s == "pi") { out = 3.14159265358979; return true; }
+        if (e.s == "tau") { out = 6.28318530717959; return true; }
+        if (e.s == "e") { out = 2.71828182845905; return true; }
+        if (e.s == "phi") { out = 1.61803398874989; return true; }
+        return false;
+    case Expr::Bin: {
+        double l, r;
+        if (!eval_js_const(e.kids[0], l) || !eval_js_const(e.kids[1], r)) return false;
+        switch (e.op) {
+        case BinOp::Add: out = l + r; break;
+        case BinOp::Sub: out = l - r; break;
+        case BinOp::Mul: out = l * r; break;
+        case BinOp::Div: out = l / r; break;
+        case BinOp::Pow: out = std::pow(l, r); break;
+        case BinOp::Gt: out = l > r ? 1.0 : 0.0; break;
+        case BinOp::Lt: out = l < r ? 1.0 : 0.0; break;
+        }
+        return true;
+    }
+    case Expr::Ternary: {
+        double c;
+        if (!eval_js_const(e.kids[0], c)) return false;
+        return eval_js_const(e.kids[truthy(c) ? 1 : 2], out);
+    }
+    case Expr::Call: {
+        std::vector<double> a(e.args.size());
+        for (size_t i = 0; i < e.args.size(); ++i) if (!eval_js_const(e.args[i].value, a[i])) return false;
+        const std::string& n = e.s;
+        const size_t k = a.size();
+        if (n == "mod" && k == 2) { out = std::fmod(a[0], a[1]); return true; }            // JS %
+        if (n == "mod" && k == 1) { out = std::fmod(a[0], 1.0); return true; }
+        if (n == "fract" && k == 1) { out = std::fmod(a[0], 1.0); return true; }
+        if (n == "abs" && k == 1) { out = std::fabs(a[0]); return true; }
+        if (n == "sin" && k == 1) { out = std::sin(a[0]); return true; }
+        if (n == "cos" && k == 1) { out = std::cos(a[0]); return true; }
+        if (n == "tan" && k == 1) { out = std::tan(a[0]); return true; }
+        if (n == "sqrt" && k == 1) { out = std::sqrt(a[0]); return true; }
+        if (n == "floor" && k == 1) { out = std::floor(a[0]); return true; }
+        if (n == "ceil" && k == 1) { out = std::ceil(a[0]); return true; }
+        if (n == "round" && k == 1) { out = std::floor(a[0] + 0.5); return true; }          // Math.round
+        if (n == "exp" && k == 1) { out = std::exp(a[0]); return true; }
+        if (n == "log" && k == 1) { out = std::log(a[0]); return true; }
+        if (n == "sign" && k == 1) { out = a[0] > 0 ? 1.0 : a[0] < 0 ? -1.0 : a[0]; return true; }
+        if (n == "min" && k >= 1) { out = a[0]; for (double v : a) out = (v != v || out != out) ? NAN : std::min(out, v); return true; }
+        if (n == "max" && k >= 1) { out = a[0]; for (double v : a) out = (v != v || out != out) ? NAN : std::max(out, v); return true; }
+        if (n == "pow" && k == 2) { out = std::pow(a[0], a[1]); return true; }
+        if (n == "atan2" && k == 2) { out = std::atan2(a[0], a[1]); return true; }
+        if (n == "mix" && k == 3) { out = a[0] + (a[1] - a[0]) * a[2]; return true; }
+        if (n == "clamp" && k == 3) { out = std::min(std::max(a[0], a[1]), a[2]); return true; }
+        if (n == "smoothstep" && k == 3) {
+            double t = std::min(std::max((a[2] - a[0]) / (a[1] - a[0]), 0.0), 1.0);
+            out = t * t * (3 - 2 * t);
+            return true;
+        }
+        if (n == "length" && k >= 1) { double s2 = 0; for (double v : a) s2 += v * v; out = std::sqrt(s2); return true; }
+        return false;
+    }
+    default: return false;   // strings, arrays, dotted names
+    }
+}
+
+namespace {
+// The seven easing curves of runtime/arc.rs:22-30; unknown names fall back to linear (`_ease[a.ease] || _ease.linear`).
+double ease(const std::string& name, double t)
+{
+    const double PI = 3.141592653589793;
+    if (name == "expo_in") return t == 0 ? 0 : std::pow(2, 10 * (t - 1));
+    if (name == "expo_out") return t == 1 ? 1 : 1 - std::pow(2, -10 * t);
+    if (name == "cubic_in_out") return t < 0.5 ? 4 * t * t * t : 1 - std::pow(-2 * t + 2, 3) / 2;
+    if (name == "smooth") return t * t * (3 - 2 * t);
+    if (name == "elastic") return t == 0 ? 0 : t == 1 ? 1 : -std::pow(2, 10 * (t - 1)) * std::sin((t - 1.1) * 5 * PI);
+    if (name == "bounce") {
+        const double n = 7.5625, d = 2.75;
+        if (t < 1 / d) return n * t * t;
+        if (t < 2 / d) { t -= 1.5 / d; return n * t * t + 0.75; }
+        if (t < 2.5 / d) { t -= 2.25 / d; return n * t * t + 0.9375; }
+        t -= 2.625 / d;
+        return n * t * t + 0.984375;
+    }
+    return t;
+}
+}  // namespace
+
+void arc_update(const Ir& ir, double time, double* params)
+{
+    for (const IrArc& a : ir.arcs) {
+        if (a.idx < 0) continue;
+        if (time < a.start) continue;
+        if (time >= a.start + a.dur) { params[a.idx] = a.to; continue; }
+        const double t = (time - a.start) / a.dur;
+        params[a.idx] = a.from + (a.to - a.from) * ease(a.easing, t);
+    }
 }
 
 // ── serialisation ────────────────────────────────────────────────────────
@@ -329,7 +456,15 @@ std::string ir_to_json(const Ir& ir)
     } else {
         j += "null";
     }
-    j += "}";
+    j += ",\"arcs\":[";
+    for (size_t i = 0; i < ir.arcs.size(); ++i) {
+        const IrArc& a = ir.arcs[i];
+        char buf[256];
+        snprintf(buf, sizeof buf, "{\"idx\":%d,\"from\":%.17g,\"to\":%.17g,\"start\":%.17g,\"dur\":%.17g,", a.idx,
+                 a.idx < 0 ? 0.0 : a.from, a.idx < 0 ? 0.0 : a.to, a.start, a.dur);
+        j += (i ? "," : "") + std::string(buf) + "\"target\":\"" + json_escape(a.target) + "\",\"ease\":\"" + json_escape(a.easing) + "\"}";
+    }
+    j += "]}";
     return j;
 }
 

@@ -94,6 +94,15 @@ uint32_t game_ir_frame_floats(const game_ir* ir);
  * (w, h), mouse = 0, user uniforms = their declared defaults. */
 void game_ir_default_uniforms(const game_ir* ir, float time_s, uint32_t w, uint32_t h, float* row);
 
+/* Arc timeline (game-compiler/src/runtime/arc.rs:52-125, emitted by the reference as the JS function
+ * arcUpdate(time, params) that its own renderer never calls): entries `target: from -> to over duration
+ * [easing]` run back to back; game_ir_arc_update applies the timeline at time_s, in JS-number (double)
+ * arithmetic, to the user-uniform part of one frame row (values are then Float32, as uploaded). Seven
+ * easings: linear, expo_in, expo_out, cubic_in_out, smooth, elastic, bounce. Entries whose target names no
+ * uniform or whose endpoints are not constant numbers are skipped, as the emitted JS skips idx < 0. */
+uint32_t game_ir_arc_count(const game_ir* ir);
+void game_ir_arc_update(const game_ir* ir, double time_s, float* row);
+
 /* Places where the reference's emitted GLSL does not compile or leaves a value undefined; the IR
  * then carries the evident intent (see front.hpp IrFlag for the per-bit meaning). */
 enum {

@@ -196,6 +196,20 @@ def test_wgsl_semantics_tables_and_sizes(game, oracle):
     check(game, oracle, C3_SHOWCASE, 128, 72, [0.5], audio={"bass": 0.8, "mid": 0.6, "treble": 0.4}, semantics="wgsl")
 
 
+def test_arc_timeline_drives_the_frames(game, oracle):
+    """Rows animated by the cinematic's own arc timeline: the frames change over time and stay bit-exact."""
+    src = ('cinematic "a" { layer { fn: circle(radius) | glow(brightness) | tint(0.2, 0.7, 0.9)\n radius: 0.05\n brightness: 0.5 } '
+           'arc { radius: 0.05 -> 0.4 over 2s expo_out\n brightness: 0.5 -> 3.0 over 1s smooth } }')
+    cin = game.compile(src).cinematics[0]
+    rows = cin.uniform_rows([0.0, 0.5, 1.0, 2.5, 4.0], 96, 54, arcs=True)
+    r = cin.renderer(96, 54)
+    got = r.render(rows)
+    r.close()
+    want = oracle.render_sequence(cin.blob, 96, 54, rows, False)
+    assert np.array_equal(got, want)
+    assert not np.array_equal(got[0], got[2]) and not np.array_equal(got[2], got[4])
+
+
 def test_gallery_memory_sequence(game, oracle):
     check(game, oracle, GALLERY["memory_multi"], 64, 36, [k / 30 for k in range(6)])
 
