@@ -199,7 +199,26 @@ def run_frames(args, torch, rank, world, local, key):
                                    "bytes_per_pixel": cfg["bytes_px"]}
             if cfg["bound"] == "valu" and not os.environ.get("GAME_HIP_NO_LUT"):
                 out["roofline"]["note"] = ("lattice hashes / voronoi points are read from per-device tables, so the algorithmic flop rate "
-                                           "can exceed the arithmetic peak; valu_issue_frac is the share of VALU issue slots actually used")
+                                           "can exceed the arithmetic peak; valu_issue_frac is the share of VALU issue slots actually used; "
+                                           "arithmetic_only is the same kernel built without the tables")
+                if world == 1 and not args.no_cpu:   # comparison legs are skipped together (--no-cpu: profiler runs)
+                    # the same workload with every hash evaluated arithmetically (no tables), a few steps, outside the main timing
+                    os.environ["GAME_HIP_NO_LUT"] = "1"
+                    r2 = cin.renderer(w, h, device=local)
+                    os.environ.pop("GAME_HIP_NO_LUT")
+                    r2.set_ring(batch)
+                    for s2 in range(3):
+                        r2.render(tables[s2 % len(tables)], readback=False)
+                    r2.sync()
+                    ms2, n2 = 0.0, 10
+                    for s2 in range(n2):
+                        r2.render(tables[s2 % len(tables)], readback=False)
+                        ms2 += r2.last_kernel_ms()[0]
+                    r2.close()
+                    sec2 = ms2 / n2 / 1e3
+                    ach2 = px_launch * cfg["flops_px"] / sec2 / 1e12
+                    out["roofline"]["arithmetic_only"] = {"value": round(px_launch / sec2 / 1e6, 1), "unit": "Mpixel/s", "achieved": round(ach2, 2),
+                                                          "frac": round(ach2 / PEAK_FP32_TFLOPS, 4), "avg_launch_ms": round(sec2 * 1e3, 4)}
             if pmc:
                 # share of the VALU issue slots (one wave64 instruction per 2 cycles per SIMD) this launch used
                 out["roofline"]["valu_issue_frac"] = round(pmc["waves_per_launch"] * pmc["valu_instructions_per_wave"] * 2.0 / (SIMDS * CLOCK_HZ * sec), 4)
