@@ -5,7 +5,10 @@
 // VGPRs from `p` to the packed RGBA8 store. Semantics follow the GLSL ES 3.00 text the reference
 // compiler emits (game-compiler/src/codegen/glsl.rs; line numbers are cited per function), one
 // FP32 rounding per GLSL operator: this file must be compiled with -ffp-contract=off, and fused
-// multiply-adds appear only where written as __builtin_fmaf (inside the sin/cos/atan kernels).
+// multiply-adds appear only where written as __builtin_fmaf: inside the sin/cos/atan/exp2/log2 kernels
+// and at the fixed contraction points (mix, the Hermite factor 3 - 2t, length, the noise remap, the fbm
+// accumulate and octave rotation, the glow halo denominator, the RGBA8 pack). GLSL leaves contraction to
+// the implementation; fixing the points makes every machine produce the same bits. hash2 is never fused.
 //
 // The file is compiled by hiprtc (no system headers) and, for the unit-test kernels, by hipcc.
 #pragma once
