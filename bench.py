@@ -302,7 +302,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS) + ["c5"])
     ap.add_argument("--batch", type=int, default=25, help="frames per step (per GPU)")
-    ap.add_argument("--particles", type=int, default=262144)
+    ap.add_argument("--particles", type=int, default=1048576)
     ap.add_argument("--no-events", dest="events", action="store_false", help="skip per-step HIP event timing")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
