@@ -9,6 +9,7 @@ import pytest
 from conftest import C1_HELLO, C4_TRAILS, ROOT
 
 GAME = os.path.join(ROOT, "game-engine_amd", "game")
+pytestmark = pytest.mark.skipif(not os.path.exists(GAME), reason="game-engine_amd/game is not built (make -C game-engine_amd)")
 
 
 def run(*args, **kw):
