@@ -67,6 +67,8 @@ def _load():
         "game_hip_set_ring": (c.c_int, [vp, u32]),
         "game_hip_render": (c.c_int, [vp, vp, u32, vp]),
         "game_hip_render_band": (c.c_int, [vp, vp, u32, u32, u32, vp]),
+        "game_hip_host_alloc": (vp, [sz]),
+        "game_hip_host_free": (None, [vp]),
         "game_hip_reset_memory": (c.c_int, [vp]),
         "game_hip_sync": (c.c_int, [vp]),
         "game_hip_frame_ptr": (vp, [vp, u32]),
@@ -260,6 +262,18 @@ def device_count():
     return n.value
 
 
+def pinned_array(shape):
+    """uint8 array in page-locked host memory (game_hip_host_alloc), released when the array is collected."""
+    import weakref
+    n = int(np.prod(shape))
+    ptr = lib.game_hip_host_alloc(n)
+    if not ptr:
+        raise GameError(81, lib.game_last_error().decode("utf-8", "replace"), "")
+    buf = (ctypes.c_ubyte * n).from_address(ptr)
+    weakref.finalize(buf, lib.game_hip_host_free, ptr)
+    return np.frombuffer(buf, dtype=np.uint8).reshape(shape)
+
+
 class Renderer:
     """GPU context for one cinematic at one resolution (reference: GameRendererGL, runtime/helpers.rs:131-241)."""
 
@@ -292,10 +306,12 @@ class Renderer:
             raise ValueError(f"uniform rows need {self.cinematic.frame_floats} floats, got {rows.shape[1]}")
         return rows
 
-    def render(self, rows, readback=True):
-        """Renders len(rows) frames; returns (nframes, h, w, 4) uint8 (top row first) or None."""
+    def render(self, rows, readback=True, pinned=False):
+        """Renders len(rows) frames; returns (nframes, h, w, 4) uint8 (top row first) or None. pinned=True
+        reads back into page-locked host memory (freed with the returned array)."""
         rows = self._rows(rows)
-        out = np.empty((rows.shape[0], self.h, self.w, 4), dtype=np.uint8) if readback else None
+        shape = (rows.shape[0], self.h, self.w, 4)
+        out = (pinned_array(shape) if pinned else np.empty(shape, dtype=np.uint8)) if readback else None
         _check(lib.game_hip_render(self._h, rows.ctypes.data, rows.shape[0], out.ctypes.data if readback else None))
         return out
 

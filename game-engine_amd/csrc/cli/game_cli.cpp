@@ -326,8 +326,17 @@ int cmd_render(const Args& a)
         if (game_hip_set_ring(ctx, game_ir_uses_memory(ir) ? 2u : batch) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
         const uint32_t nf = game_ir_frame_floats(ir);
         std::vector<float> rows((size_t)batch * nf);
-        std::vector<uint8_t> host;
-        if (!a.out.empty()) host.resize((size_t)batch * a.w * a.h * 4);
+        // frames come back into page-locked memory (DMA at PCIe rate)
+        struct Pinned {
+            uint8_t* p = nullptr;
+            ~Pinned() { game_hip_host_free(p); }
+            bool empty() const { return p == nullptr; }
+            uint8_t* data() const { return p; }
+        } host;
+        if (!a.out.empty()) {
+            host.p = (uint8_t*)game_hip_host_alloc((size_t)batch * a.w * a.h * 4);
+            if (!host.p) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
+        }
         auto t0 = std::chrono::steady_clock::now();
         double device_ms = 0;
         bool ok = true;

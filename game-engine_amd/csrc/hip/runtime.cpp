@@ -487,6 +487,20 @@ int game_hip_last_kernel_ms(game_hip_ctx* c, float* ms, uint32_t* launches)
     return GAME_OK;
 }
 
+void* game_hip_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (bytes == 0) { set_error(GAME_E_ARGUMENT, "game_hip_host_alloc: zero bytes"); return nullptr; }
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { hip_fail("hipHostMalloc", e); return nullptr; }
+    return p;
+}
+
+void game_hip_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 const char* game_hip_kernel_source(const game_hip_ctx* c) { return c ? c->source.c_str() : ""; }
 
 // ── particles ────────────────────────────────────────────────────────────────────────────

@@ -155,6 +155,11 @@ int game_hip_render(game_hip_ctx* ctx, const float* uniforms, uint32_t nframes, 
  * not touched. rgba8_host, when non-NULL, receives only the band (nframes * rows * w * 4). */
 int game_hip_render_band(game_hip_ctx* ctx, const float* uniforms, uint32_t nframes, uint32_t row0,
                          uint32_t rows, uint8_t* rgba8_host);
+/* Page-locked host memory for the rgba8_host argument: frames then leave the GPU by DMA at PCIe rate
+ * instead of through the staged copy a pageable buffer gets (about 4x faster on the tested host). Any host
+ * pointer is accepted by the render calls; this pair is a convenience around hipHostMalloc / hipHostFree. */
+void* game_hip_host_alloc(size_t bytes);
+void game_hip_host_free(void* p);
 int game_hip_reset_memory(game_hip_ctx* ctx);          /* previous-frame store := 0 */
 int game_hip_sync(game_hip_ctx* ctx);                  /* wait for the context's stream */
 void* game_hip_frame_ptr(game_hip_ctx* ctx, uint32_t slot);   /* device pointer of a ring slot */

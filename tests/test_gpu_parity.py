@@ -196,6 +196,15 @@ def test_wgsl_semantics_tables_and_sizes(game, oracle):
     check(game, oracle, C3_SHOWCASE, 128, 72, [0.5], audio={"bass": 0.8, "mid": 0.6, "treble": 0.4}, semantics="wgsl")
 
 
+def test_page_locked_readback_equals_pageable(game):
+    cin = game.compile(C1_HELLO).cinematics[0]
+    rows = cin.uniform_rows([0.0, 0.5, 1.0], 200, 120)
+    r = cin.renderer(200, 120)
+    a, b = r.render(rows), r.render(rows, pinned=True)
+    r.close()
+    assert np.array_equal(a, b)
+
+
 def test_arc_timeline_drives_the_frames(game, oracle):
     """Rows animated by the cinematic's own arc timeline: the frames change over time and stay bit-exact."""
     src = ('cinematic "a" { layer { fn: circle(radius) | glow(brightness) | tint(0.2, 0.7, 0.9)\n radius: 0.05\n brightness: 0.5 } '

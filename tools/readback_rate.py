@@ -12,8 +12,10 @@ cin = g.compile(cfg["src"]).cinematics[0]
 w, h, batch = cfg["w"], cfg["h"], 8
 r = cin.renderer(w, h); r.set_ring(2 if cin.uses_memory else batch)
 rows = cin.uniform_rows([k / 60 for k in range(batch)], w, h)
-r.render(rows)                      # warm-up (pins nothing: plain host buffer)
-t0 = time.perf_counter(); n = 3
-for _ in range(n): r.render(rows)
-dt = time.perf_counter() - t0
-print(f"{key}: {n*batch} frames {w}x{h} rendered and read back in {dt:.3f} s -> {n*batch*w*h/dt/1e6:.0f} Mpixel/s, {n*batch*w*h*4/dt/1e9:.2f} GB/s to host")
+for pinned in (False, True):
+    r.render(rows, pinned=pinned)       # warm-up
+    t0 = time.perf_counter(); n = 3
+    for _ in range(n): out = r.render(rows, pinned=pinned)
+    dt = time.perf_counter() - t0
+    print(f"{key} [{'page-locked' if pinned else 'pageable'} host buffer]: {n*batch} frames {w}x{h} rendered and read back in {dt:.3f} s -> "
+          f"{n*batch*w*h/dt/1e6:.0f} Mpixel/s, {n*batch*w*h*4/dt/1e9:.2f} GB/s to host")
