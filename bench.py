@@ -49,7 +49,7 @@ def measured_counters(key, frames_per_launch):
 # Algorithmic work per pixel (flop convention: add/sub/mul/div/min/max/abs/floor/fract/compare/select
 # = 1, sin/cos/sqrt/atan = 1, mul+add pair = 2), summed over the stages of each cinematic.
 CONFIGS = {
-    "c1": dict(src=T.C1_HELLO, w=1024, h=1024, flops_px=47, bytes_px=4, bound="hbm",
+    "c1": dict(src=T.C1_HELLO, w=1024, h=1024, flops_px=47, bytes_px=4, bound="hbm", batch=200,
                workload="examples/001-hello.game circle|glow|tint, 1024x1024"),
     "c2": dict(src=T.C2_FBM, w=3840, h=2160, flops_px=1006, bytes_px=4, bound="valu",
                workload="fbm showcase: domain_warp(0.1,3.0)|fbm(3.0,octaves:6,0.5,2.0)|glow(1.5)|tint, 3840x2160, frame-sharded"),
@@ -124,7 +124,7 @@ def run_frames(args, torch, rank, world, local, key):
     cin = game.compile(cfg["src"]).cinematics[0]
     w, h = cfg["w"], cfg["h"]
     banded = cin.uses_memory
-    batch = args.batch
+    batch = args.batch if args.batch else cfg.get("batch", 25)
     if banded:
         # horizontal bands, multiples of 8 rows; every rank renders every frame of its band. The
         # feedback read is the same pixel of the previous frame, so no halo rows are exchanged.
@@ -301,7 +301,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS) + ["c5"])
-    ap.add_argument("--batch", type=int, default=25, help="frames per step (per GPU)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step (per GPU); default 25 (200 for the 1024x1024 config)")
     ap.add_argument("--particles", type=int, default=1048576)
     ap.add_argument("--no-events", dest="events", action="store_false", help="skip per-step HIP event timing")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
