@@ -144,9 +144,9 @@ void game_hip_destroy(game_hip_ctx* ctx);
  * consecutive frames. `uniforms` holds nframes rows of game_ir_frame_floats() floats (host memory).
  * Frames are RGBA8, row 0 = TOP row of the image (the GL framebuffer's row 0 is the bottom row;
  * the flip happens when the kernel stores a pixel). Frames land in a device ring of `ring_frames`
- * slots (frame k of this call -> slot (first_slot + k) % ring_frames); when rgba8_host is non-NULL
- * every frame is also copied to host memory (nframes * w * h * 4 bytes; needs nframes <=
- * ring_frames). Cinematics with `memory:` layers are frame-serial: each frame reads the previous
+ * slots (frame k of this call -> slot (first_slot + k) % ring_frames; a call may render more frames
+ * than the ring holds, in ring-sized launches); when rgba8_host is non-NULL every frame is also copied
+ * to host memory in stream order, before its slot is reused (nframes * w * h * 4 bytes). Cinematics with `memory:` layers are frame-serial: each frame reads the previous
  * frame's RGBA8 output (zero before the first frame; see game_hip_reset_memory). */
 int game_hip_set_ring(game_hip_ctx* ctx, uint32_t ring_frames);
 int game_hip_render(game_hip_ctx* ctx, const float* uniforms, uint32_t nframes, uint8_t* rgba8_host);
