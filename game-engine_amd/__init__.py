@@ -58,6 +58,8 @@ def _load():
         "game_ir_has_gravity": (c.c_int, [vp]),
         "game_ir_frame_floats": (u32, [vp]),
         "game_ir_default_uniforms": (None, [vp, f32, u32, u32, vp]),
+        "game_ir_derived_count": (u32, [vp]),
+        "game_ir_eval_derived": (None, [vp, vp, vp]),
         "game_ir_arc_count": (u32, [vp]),
         "game_ir_arc_update": (None, [vp, c.c_double, vp]),
         "game_hip_device_count": (c.c_int, [c.POINTER(c.c_int)]),
@@ -98,6 +100,7 @@ lib, EXPORTED_SYMBOLS = _load()
 
 
 SEMANTICS = {"glsl": 0, "wgsl": 1}   # GAME_HIP_SEMANTICS_WGSL
+ANIMATE_ARGS = 2                     # GAME_HIP_ANIMATE_ARGS
 
 
 def _check(rc):
@@ -172,19 +175,33 @@ class Cinematic:
     def arc_count(self):
         return lib.game_ir_arc_count(self._h)
 
-    def compile_only(self, semantics="glsl"):
+    @property
+    def derived_count(self):
+        """Number of expression-valued stage arguments kept as per-frame programs."""
+        return lib.game_ir_derived_count(self._h)
+
+    def eval_derived(self, rows):
+        """Per-frame values of those arguments for an (n, frame_floats) float32 array of uniform rows."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        out = np.zeros((rows.shape[0], self.derived_count), dtype=np.float32)
+        for k in range(rows.shape[0]):
+            lib.game_ir_eval_derived(self._h, rows[k].ctypes.data, out[k].ctypes.data)
+        return out
+
+    def compile_only(self, semantics="glsl", animate=False):
         """hiprtc-compiles the generated kernels for gfx950 without a device; returns code bytes."""
         n = ctypes.c_size_t()
-        _check(lib.game_hip_compile_only_ex(self._h, SEMANTICS[semantics], ctypes.byref(n)))
+        _check(lib.game_hip_compile_only_ex(self._h, SEMANTICS[semantics] | (ANIMATE_ARGS if animate else 0), ctypes.byref(n)))
         return n.value
 
     def dump_code(self, path_prefix):
         """Writes the generated kernel source and gfx950 code object next to `path_prefix`."""
         _check(lib.game_hip_dump_code(self._h, path_prefix.encode()))
 
-    def renderer(self, w, h, device=0, semantics="glsl"):
-        """semantics: "glsl" = the reference's WebGL2 wording of the builtins (default), "wgsl" = its WebGPU wording."""
-        return Renderer(self, w, h, device, semantics)
+    def renderer(self, w, h, device=0, semantics="glsl", animate=False):
+        """semantics: "glsl" = the reference's WebGL2 wording of the builtins (default), "wgsl" = its WebGPU wording.
+        animate: expression-valued stage arguments take their per-frame value instead of the parameter default."""
+        return Renderer(self, w, h, device, semantics, animate)
 
 
 class Program:
@@ -277,11 +294,11 @@ def pinned_array(shape):
 class Renderer:
     """GPU context for one cinematic at one resolution (reference: GameRendererGL, runtime/helpers.rs:131-241)."""
 
-    def __init__(self, cinematic, w, h, device=0, semantics="glsl"):
+    def __init__(self, cinematic, w, h, device=0, semantics="glsl", animate=False):
         self.cinematic = cinematic
         self.w, self.h = w, h
         h_ = ctypes.c_void_p()
-        _check(lib.game_hip_create_ex(cinematic._h, w, h, device, SEMANTICS[semantics], ctypes.byref(h_)))
+        _check(lib.game_hip_create_ex(cinematic._h, w, h, device, SEMANTICS[semantics] | (ANIMATE_ARGS if animate else 0), ctypes.byref(h_)))
         self._h = h_
 
     def close(self):

@@ -10,7 +10,8 @@
 //                                        --out writes PREFIX_00000.ppm ... (binary P6, RGB of the RGBA8 frame),
 //                                        or PREFIX_00000.png (8-bit RGBA, stored deflate blocks) with --png;
 //                                        the cinematic's arc timeline (runtime/arc.rs) drives its parameters unless
-//                                        --no-arcs; --semantics wgsl renders the builtins as the reference's WebGPU emitter
+//                                        --no-arcs; --animate evaluates expression-valued stage arguments per frame
+//                                        (the reference's emitters use the parameter defaults); --semantics wgsl renders the builtins as the reference's WebGPU emitter
 //                                        words them (wgsl.rs:268-540) instead of its WebGL2 emitter
 //   game compare A B [--threshold T]     two frames (.ppm or .png written by this tool): share of pixels whose
 //                                        channels all differ by <= T (the measure of snapshot.rs:240-258,
@@ -51,7 +52,7 @@ int usage()
             "usage: game check FILE...\n"
             "       game render FILE --hip [--size WxH] [--frames N] [--fps F] [--batch B] [--device D]\n"
             "                   [--cinematic I] [--out PREFIX] [--particles N --steps S]\n"
-            "                   [--png] [--semantics glsl|wgsl] [--no-arcs]\n"
+            "                   [--png] [--semantics glsl|wgsl] [--no-arcs] [--animate]\n"
             "       game compare A B [--threshold T]\n"
             "       game ir FILE | game kernel FILE [--size WxH] | game builtins\n");
     return 2;
@@ -59,7 +60,7 @@ int usage()
 
 struct Args {
     std::vector<std::string> files;
-    bool hip = false, png = false, wgsl = false, arcs = true;
+    bool hip = false, png = false, wgsl = false, arcs = true, animate = false;
     int threshold = 2;
     uint32_t w = 1920, h = 1080, frames = 60, batch = 16, cinematic = 0, particles = 0, steps = 1;
     double fps = 60.0;
@@ -78,6 +79,7 @@ bool parse_args(int argc, char** argv, int first, Args& a)
         if (s == "--hip") a.hip = true;
         else if (s == "--png") a.png = true;
         else if (s == "--no-arcs") a.arcs = false;
+        else if (s == "--animate") a.animate = true;
         else if (s == "--semantics") {
             const char* v = value("--semantics");
             if (!v) return false;
@@ -308,7 +310,7 @@ int cmd_render(const Args& a)
     do {
         if (a.cinematic >= game_program_cinematic_count(prog)) { fprintf(stderr, "game render: no cinematic %u\n", a.cinematic); break; }
         const game_ir* ir = game_program_ir(prog, a.cinematic);
-        if (game_hip_create_ex(ir, a.w, a.h, a.device, a.wgsl ? (uint32_t)GAME_HIP_SEMANTICS_WGSL : 0u, &ctx) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
+        if (game_hip_create_ex(ir, a.w, a.h, a.device, (a.wgsl ? (uint32_t)GAME_HIP_SEMANTICS_WGSL : 0u) | (a.animate ? (uint32_t)GAME_HIP_ANIMATE_ARGS : 0u), &ctx) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
         if (a.particles) {
             if (game_hip_particles_seed(ctx, a.particles, 0x9E3779B97F4A7C15ull) != GAME_OK ||
                 game_hip_particles_step(ctx, (float)(1.0 / a.fps), a.steps, 0, a.particles) != GAME_OK || game_hip_sync(ctx) != GAME_OK) {

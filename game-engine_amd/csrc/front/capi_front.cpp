@@ -126,6 +126,13 @@ void game_ir_default_uniforms(const game_ir* ir, float time_s, uint32_t w, uint3
     for (size_t i = 0; i < ir->ir->uniforms.size(); ++i) row[BU_COUNT + i] = (float)ir->ir->uniforms[i].def;
 }
 
+uint32_t game_ir_derived_count(const game_ir* ir) { return ir ? (uint32_t)ir->ir->derived.size() : 0; }
+
+void game_ir_eval_derived(const game_ir* ir, const float* row, float* out)
+{
+    if (ir && row && out) eval_derived(*ir->ir, row, out);
+}
+
 uint32_t game_ir_arc_count(const game_ir* ir) { return ir ? (uint32_t)ir->ir->arcs.size() : 0; }
 
 void game_ir_arc_update(const game_ir* ir, double time_s, float* row)

@@ -178,7 +178,11 @@ struct UniformInfo { std::string name; double def = 0.0; };                 // c
 std::vector<UniformInfo> extract_uniforms(const Cinematic& c);              // codegen/mod.rs:54
 
 // Text the reference would paste into the shader for one stage argument (stages.rs:8-42).
-struct ArgText { enum Kind : uint8_t { Literal, Ident, Dotted } kind = Literal; std::string text; };
+struct ArgText {
+    enum Kind : uint8_t { Literal, Ident, Dotted } kind = Literal;
+    std::string text;
+    const Expr* dropped = nullptr;   // the expression stages.rs:8-22 replaces by the default (not Number / Ident / Dotted)
+};
 ArgText get_arg(const std::vector<Arg>& args, const char* name, size_t pos, const char* stage_name);
 std::string fmt_fixed6(double v);                                           // Rust `{v:.6}`
 
@@ -210,7 +214,10 @@ enum IrFlag : uint32_t {
     IRF_COLOR_BEFORE_DECL= 1u << 9,  // a Sdf/Color-input stage is reached with that value undeclared
 };
 
-struct IrArg { uint32_t kind = ARG_LIT; uint32_t slot = 0; float lit = 0.0f; std::string text; };
+// derived >= 0: the source wrote an expression here. The reference's emitters drop it for the parameter's
+// default (kind/slot/lit above hold that); a context created with GAME_HIP_ANIMATE_ARGS instead evaluates
+// Ir::derived[derived] on the host once per frame and passes the value as an extra uniform.
+struct IrArg { uint32_t kind = ARG_LIT; uint32_t slot = 0; float lit = 0.0f; std::string text; int derived = -1; };
 struct IrStage { uint16_t builtin = 0; uint32_t nargs = 0; IrArg args[4]; uint32_t aux = 0; std::string name; };
 struct IrLayer {
     std::string name;
@@ -220,7 +227,7 @@ struct IrLayer {
     State end_state = State::Position;
 };
 enum LawOp : uint32_t { LAW_NUM = 0, LAW_DIST, LAW_TIME, LAW_ADD, LAW_SUB, LAW_MUL, LAW_DIV, LAW_POW, LAW_GT, LAW_LT,
-                        LAW_NEG, LAW_CALL1, LAW_CALL2, LAW_CALL3 };
+                        LAW_NEG, LAW_CALL1, LAW_CALL2, LAW_CALL3, LAW_UNIFORM };
 enum LawFn : uint32_t { LF_SIN = 0, LF_COS, LF_TAN, LF_ABS, LF_SQRT, LF_EXP, LF_LOG, LF_FLOOR, LF_CEIL, LF_FRACT, LF_SIGN,
                         LF_MIN, LF_MAX, LF_POW, LF_STEP, LF_CLAMP, LF_MIX, LF_SMOOTHSTEP, LF_EXP2, LF_LOG2, LF_COUNT };
 struct IrLawOp { uint32_t op = LAW_NUM; float val = 0.0f; uint32_t fn = 0; };
@@ -241,6 +248,10 @@ struct IrArc {
     std::string easing;
 };
 
+// A frame-level scalar expression in reverse Polish form (the operators and functions of IrLawOp; LAW_UNIFORM
+// pushes slot `fn` of the frame row, where slot 0 is the wrapped time the shader calls `time`).
+struct IrDerived { std::vector<IrLawOp> prog; std::string text; };
+
 struct Ir {
     std::string name;
     bool multi_layer = false;     // cinematic.layers.len() > 1, params layers included (glsl.rs:66)
@@ -251,7 +262,11 @@ struct Ir {
     IrGravity gravity;
     bool uses_memory = false;
     std::vector<IrArc> arcs;
+    std::vector<IrDerived> derived;
 };
+
+// Values of Ir::derived for one frame row (10 built-ins + user uniforms), f32 arithmetic.
+void eval_derived(const Ir& ir, const float* row, float* out);
 
 // arcUpdate(time, params) of runtime/arc.rs:110-122 in JS number (double) arithmetic: applies the timeline to
 // `params` (one value per uniform, in uniform order).

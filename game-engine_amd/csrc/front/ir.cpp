@@ -110,7 +110,127 @@ void lower_law(const Expr& e, Ir& ir)
     }
 }
 
+// The expression as the source would spell it (for the IR's JSON view and diagnostics).
+std::string expr_source_text(const Expr& e)
+{
+    switch (e.kind) {
+    case Expr::Number: return fmt_fixed6(e.num);
+    case Expr::Ident: return e.s;
+    case Expr::Dotted: return e.s + "." + e.field;
+    case Expr::Paren: return "(" + expr_source_text(e.kids[0]) + ")";
+    case Expr::Neg: return "-" + expr_source_text(e.kids[0]);
+    case Expr::Bin: {
+        static const char* const ops[] = {" + ", " - ", " * ", " / ", " ^ ", " > ", " < "};
+        return "(" + expr_source_text(e.kids[0]) + ops[(int)e.op] + expr_source_text(e.kids[1]) + ")";
+    }
+    case Expr::Call: {
+        std::string t = e.s + "(";
+        for (size_t i = 0; i < e.args.size(); ++i) t += (i ? ", " : "") + expr_source_text(e.args[i].value);
+        return t + ")";
+    }
+    default: return "?";
+    }
+}
+
+// Frame-level scalar expression -> RPN; false when it reads something that is not a frame constant
+// (`p`, `uv`, an unknown name, a string, an array) or calls an unknown function.
+bool lower_frame_expr(const Expr& e, const std::map<std::string, uint32_t>& uslot, std::vector<IrLawOp>& prog)
+{
+    auto push = [&](uint32_t op, float v = 0.0f, uint32_t fn = 0) { IrLawOp o; o.op = op; o.val = v; o.fn = fn; prog.push_back(o); };
+    switch (e.kind) {
+    case Expr::Number: push(LAW_NUM, (float)e.num); return true;
+    case Expr::Dur: push(LAW_NUM, (float)(e.dur.kind == DurKind::Seconds ? e.dur.v : e.dur.kind == DurKind::Millis ? e.dur.v / 1000.0 : (double)e.dur.bars * 2.0)); return true;
+    case Expr::Ident: {
+        if (e.s == "time") { push(LAW_UNIFORM, 0.0f, BU_TIME); return true; }
+        static const struct { const char* n; float v; } consts[] = {   // expr.rs:39-47
+            {"pi", 3.14159265358979f}, {"tau", 6.28318530717959f}, {"e", 2.71828182845905f}, {"phi", 1.61803398874989f}};
+        for (auto& k : consts) if (e.s == k.n) { push(LAW_NUM, k.v); return true; }
+        auto it = uslot.find(e.s);
+        if (it == uslot.end()) return false;
+        push(LAW_UNIFORM, 0.0f, BU_COUNT + it->second);
+        return true;
+    }
+    case Expr::Dotted: {
+        static const struct { const char* o; const char* f; uint32_t slot; } dotted[] = {
+            {"audio", "bass", BU_AUDIO_BASS}, {"audio", "mid", BU_AUDIO_MID}, {"audio", "treble", BU_AUDIO_TREBLE},
+            {"audio", "energy", BU_AUDIO_ENERGY}, {"audio", "beat", BU_AUDIO_BEAT}, {"mouse", "x", BU_MOUSE_X}, {"mouse", "y", BU_MOUSE_Y}};
+        for (auto& d : dotted) if (e.s == d.o && e.field == d.f) { push(LAW_UNIFORM, 0.0f, d.slot); return true; }
+        return false;
+    }
+    case Expr::Paren: return lower_frame_expr(e.kids[0], uslot, prog);
+    case Expr::Neg: if (!lower_frame_expr(e.kids[0], uslot, prog)) return false; push(LAW_NEG); return true;
+    case Expr::Bin: {
+        if (!lower_frame_expr(e.kids[0], uslot, prog) || !lower_frame_expr(e.kids[1], uslot, prog)) return false;
+        static const uint32_t ops[] = {LAW_ADD, LAW_SUB, LAW_MUL, LAW_DIV, LAW_POW, LAW_GT, LAW_LT};
+        push(ops[(int)e.op]);
+        return true;
+    }
+    case Expr::Call: {
+        bool ok;
+        LawFn f = law_fn(e.s, e.args.size(), ok);
+        if (!ok) return false;
+        for (const Arg& a : e.args) if (!lower_frame_expr(a.value, uslot, prog)) return false;
+        push(e.args.size() == 1 ? LAW_CALL1 : e.args.size() == 2 ? LAW_CALL2 : LAW_CALL3, 0.0f, f);
+        return true;
+    }
+    default: return false;
+    }
+}
+
 }  // namespace
+
+// Arithmetic is binary64 with the C library's functions, as a JavaScript host would compute a uniform
+// before handing it to the shader (the same convention as the arc timeline); `time` is the f32 value the
+// shader itself sees (u_time wrapped to [0,120), glsl.rs:56); each result is rounded to f32 once.
+void eval_derived(const Ir& ir, const float* row, float* out)
+{
+    auto call = [](uint32_t fn, double a, double b, double c) -> double {
+        switch (fn) {
+        case LF_SIN: return sin(a); case LF_COS: return cos(a); case LF_TAN: return tan(a); case LF_ABS: return fabs(a);
+        case LF_SQRT: return sqrt(a); case LF_EXP: return exp(a); case LF_LOG: return log(a); case LF_FLOOR: return floor(a);
+        case LF_CEIL: return ceil(a); case LF_FRACT: return a - floor(a); case LF_SIGN: return a > 0.0 ? 1.0 : a < 0.0 ? -1.0 : 0.0;
+        case LF_EXP2: return exp2(a); case LF_LOG2: return log2(a);
+        case LF_MIN: return a < b ? a : b; case LF_MAX: return a > b ? a : b; case LF_POW: return pow(a, b);
+        case LF_STEP: return b < a ? 0.0 : 1.0;
+        case LF_CLAMP: { double lo = a > b ? a : b; return lo < c ? lo : c; }
+        case LF_MIX: return a * (1.0 - c) + b * c;
+        case LF_SMOOTHSTEP: { double t = (c - a) / (b - a); t = t < 0.0 ? 0.0 : t > 1.0 ? 1.0 : t; return t * t * (3.0 - 2.0 * t); }
+        default: return 0.0;
+        }
+    };
+    for (size_t d = 0; d < ir.derived.size(); ++d) {
+        double st[64];
+        int sp = 0;
+        for (const IrLawOp& o : ir.derived[d].prog) {
+            switch (o.op) {
+            case LAW_NUM: st[sp++] = (double)o.val; break;
+            case LAW_UNIFORM: {
+                float v = row[o.fn];
+                if (o.fn == BU_TIME) {
+                    float q = v / 120.0f, f = q - floorf(q);
+                    if (f == f && !(f < 1.0f)) f = 0x1.fffffep-1f;
+                    v = f * 120.0f;
+                }
+                st[sp++] = (double)v;
+                break;
+            }
+            case LAW_ADD: sp--; st[sp - 1] = st[sp - 1] + st[sp]; break;
+            case LAW_SUB: sp--; st[sp - 1] = st[sp - 1] - st[sp]; break;
+            case LAW_MUL: sp--; st[sp - 1] = st[sp - 1] * st[sp]; break;
+            case LAW_DIV: sp--; st[sp - 1] = st[sp - 1] / st[sp]; break;
+            case LAW_POW: sp--; st[sp - 1] = pow(st[sp - 1], st[sp]); break;
+            case LAW_GT: sp--; st[sp - 1] = st[sp - 1] > st[sp] ? 1.0 : 0.0; break;
+            case LAW_LT: sp--; st[sp - 1] = st[sp - 1] < st[sp] ? 1.0 : 0.0; break;
+            case LAW_NEG: st[sp - 1] = -st[sp - 1]; break;
+            case LAW_CALL1: st[sp - 1] = call(o.fn, st[sp - 1], 0.0, 0.0); break;
+            case LAW_CALL2: sp--; st[sp - 1] = call(o.fn, st[sp - 1], st[sp], 0.0); break;
+            case LAW_CALL3: sp -= 2; st[sp - 1] = call(o.fn, st[sp - 1], st[sp], st[sp + 1]); break;
+            default: break;
+            }
+        }
+        out[d] = (float)st[0];
+    }
+}
 
 Ir lower_cinematic(const Cinematic& c)
 {
@@ -174,6 +294,16 @@ Ir lower_cinematic(const Cinematic& c)
                         if (b->id == B_PALETTE) { a.kind = ARG_LIT; a.lit = 0.0f; found = true; }
                         else ir.flags |= IRF_DOTTED_ARG;
                         if (!found) { a.kind = ARG_LIT; a.lit = 0.0f; ir.flags |= IRF_UNKNOWN_DOTTED; }
+                    }
+                    // an expression the emitters drop: keep it as a frame-level program when it is one
+                    // (not for palette names or the fbm octave count, which must stay compile-time values)
+                    if (t.dropped && b->id != B_PALETTE && !(b->id == B_FBM && p == 1)) {
+                        IrDerived d;
+                        if (lower_frame_expr(*t.dropped, uslot, d.prog) && d.prog.size() < 48) {
+                            d.text = expr_source_text(*t.dropped);
+                            a.derived = (int)ir.derived.size();
+                            ir.derived.push_back(std::move(d));
+                        }
                     }
                 }
                 if (b->id == B_PALETTE) is.aux = palette_index(is.args[0].text);
@@ -395,7 +525,7 @@ std::vector<uint8_t> ir_serialize(const Ir& ir)
             put_u32(b, s.args[i].kind);
             put_u32(b, s.args[i].slot);
             put_f32(b, s.args[i].lit);
-            put_u32(b, 0);
+            put_u32(b, (uint32_t)(s.args[i].derived + 1));   // 0 = none, else index + 1 into the derived values
         }
     }
     for (const UniformInfo& u : ir.uniforms) {
@@ -443,7 +573,7 @@ std::string ir_to_json(const Ir& ir)
                 const IrArg& ia = s.args[a];
                 const char* kind = ia.kind == ARG_LIT ? "lit" : ia.kind == ARG_USER ? "user" : "builtin";
                 j += "{\"kind\":\"" + std::string(kind) + "\",\"slot\":" + std::to_string(ia.slot) + ",\"lit\":" + f32_json(ia.lit) +
-                     ",\"text\":\"" + json_escape(ia.text) + "\"}";
+                     ",\"text\":\"" + json_escape(ia.text) + "\",\"derived\":" + std::to_string(ia.derived) + "}";
             }
             j += "]}";
         }
@@ -456,6 +586,9 @@ std::string ir_to_json(const Ir& ir)
     } else {
         j += "null";
     }
+    j += ",\"derived\":[";
+    for (size_t i = 0; i < ir.derived.size(); ++i) j += (i ? ",\"" : "\"") + json_escape(ir.derived[i].text) + "\"";
+    j += "]";
     j += ",\"arcs\":[";
     for (size_t i = 0; i < ir.arcs.size(); ++i) {
         const IrArc& a = ir.arcs[i];

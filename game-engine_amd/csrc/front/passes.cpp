@@ -558,7 +558,7 @@ static ArgText resolve_arg(const Arg& a, size_t pos, const char* stage_name)
     case Expr::Number: t.text = fmt_fixed6(a.value.num); return t;
     case Expr::Ident: t.kind = ArgText::Ident; t.text = a.value.s; return t;
     case Expr::Dotted: t.kind = ArgText::Dotted; t.text = a.value.s + "_" + a.value.field; return t;
-    default: return default_text(stage_name, pos);
+    default: t = default_text(stage_name, pos); t.dropped = &a.value; return t;
     }
 }
 

@@ -23,9 +23,10 @@ std::string float_literal(float v)
 namespace {
 
 // Frame-row layout used by the kernels: the caller's 10 + n floats, then two derived values the
-// host computes once per frame (glsl.rs:55-56).
-std::string arg_expr(const IrArg& a)
+// host computes once per frame (glsl.rs:55-56), then (animate shapes only) one float per derived value.
+std::string arg_expr(const IrArg& a, const KernelShape& shape)
 {
+    if (shape.animate && a.derived >= 0) return "U[" + std::to_string(shape.derived_slot + (uint32_t)a.derived) + "]";
     switch (a.kind) {
     case ARG_LIT: return float_literal(a.lit);
     case ARG_USER: return "U[" + std::to_string(BU_COUNT + a.slot) + "]";
@@ -64,9 +65,10 @@ bool has_wgsl_variant(uint16_t b)
     }
 }
 
-std::string stage_call(const IrStage& st, bool wgsl)
+std::string stage_call(const IrStage& st, const KernelShape& shape)
 {
-    auto A = [&](int i) { return arg_expr(st.args[i]); };
+    const bool wgsl = shape.wgsl;
+    auto A = [&](int i) { return arg_expr(st.args[i], shape); };
     auto call = [&](const char* fn, int n) {
         std::string name(fn);
         if (wgsl && has_wgsl_variant(st.builtin)) name[1] = 'w';   // gb_xxx -> gw_xxx
@@ -188,7 +190,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
         k += "    {   // layer " + std::to_string(li) + "\n";
         k += "        s.px = s.uvx * aspect; s.py = s.uvy; s.sdf = 0.0f; s.r = s.g = s.b = s.a = 0.0f;\n";
         for (uint32_t si = 0; si < L.stage_count; ++si)
-            k += "        " + stage_call(ir.stages[L.stage_begin + si], shape.wgsl) + "\n";
+            k += "        " + stage_call(ir.stages[L.stage_begin + si], shape) + "\n";
         if (L.has_memory) k += "        gb_memory_mix(s, prev, " + float_literal(L.decay) + ");\n";
         if (ir.multi_layer) {
             k += "        fr = fr + s.r - fr * s.r; fg = fg + s.g - fg * s.g; fb = fb + s.b - fb * s.b; fa = 1.0f;\n";

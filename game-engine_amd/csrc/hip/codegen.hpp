@@ -10,6 +10,8 @@ struct KernelShape {
     uint32_t time_slot = 0;         // index in the frame row of fract(u_time/120)*120
     uint32_t aspect_slot = 0;       // index in the frame row of u_resolution.x / u_resolution.y
     bool wgsl = false;              // builtins as worded by the reference's WebGPU emitter (wgsl.rs) where they differ
+    bool animate = false;           // expression-valued stage arguments read their per-frame value (Ir::derived)
+    uint32_t derived_slot = 0;      // index in the frame row of derived value 0
 };
 
 std::string float_literal(float v);

@@ -166,6 +166,8 @@ KernelShape shape_for(const Ir& ir, uint32_t width, uint32_t flags = 0)
     uint32_t row = BU_COUNT + (uint32_t)ir.uniforms.size();
     s.time_slot = row;
     s.aspect_slot = row + 1;
+    s.animate = (flags & GAME_HIP_ANIMATE_ARGS) != 0 && !ir.derived.empty();
+    s.derived_slot = row + 2;
     return s;
 }
 
@@ -200,6 +202,7 @@ int upload_rows(game_hip_ctx* c, const float* uniforms, uint32_t nframes)
         memcpy(dst, src, (size_t)c->row_floats * 4);
         dst[c->shape.time_slot] = host_fract(src[BU_TIME] / 120.0f) * 120.0f;   // glsl.rs:56
         dst[c->shape.aspect_slot] = src[BU_RES_X] / src[BU_RES_Y];              // glsl.rs:55
+        if (c->shape.animate) eval_derived(c->ir, src, dst + c->shape.derived_slot);
     }
     if (need > c->utab_cap) {
         if (c->utab_dev) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->utab_dev)); c->utab_dev = nullptr; }
@@ -354,7 +357,7 @@ int game_hip_create(const game_ir* ir, uint32_t width, uint32_t height, int devi
 int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int device, uint32_t flags, game_hip_ctx** out)
 {
     if (!ir || !out) return set_error(GAME_E_ARGUMENT, "game_hip_create: null argument");
-    if (flags & ~(uint32_t)GAME_HIP_SEMANTICS_WGSL) return set_error(GAME_E_ARGUMENT, "game_hip_create_ex: unknown flag");
+    if (flags & ~(uint32_t)(GAME_HIP_SEMANTICS_WGSL | GAME_HIP_ANIMATE_ARGS)) return set_error(GAME_E_ARGUMENT, "game_hip_create_ex: unknown flag");
     *out = nullptr;
     if (width == 0 || height == 0 || width > 65536 || height > 65535)
         return set_error(GAME_E_ARGUMENT, "game_hip_create: width must be in 1..65536 and height in 1..65535");
@@ -371,7 +374,7 @@ int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int d
     c->w = width; c->h = height;
     c->shape = shape_for(c->ir, c->w, flags);
     c->row_floats = BU_COUNT + (uint32_t)c->ir.uniforms.size();
-    c->ustride = c->row_floats + 2;
+    c->ustride = c->row_floats + 2 + (c->shape.animate ? (uint32_t)c->ir.derived.size() : 0u);
     c->source = generate_frame_kernel(c->ir, c->shape);
     std::vector<char> code;
     int rc = compile_hip(c->source, "game_frame.hip", code);

@@ -94,6 +94,16 @@ uint32_t game_ir_frame_floats(const game_ir* ir);
  * (w, h), mouse = 0, user uniforms = their declared defaults. */
 void game_ir_default_uniforms(const game_ir* ir, float time_s, uint32_t w, uint32_t h, float* row);
 
+/* Expression-valued stage arguments (`rotate(time * 1.5)`, `circle(0.15 + sin(time * 2.0) * 0.03)`): the
+ * reference's emitters replace them by the parameter's default (codegen/stages.rs:8-22) although its
+ * expression compiler (codegen/expr.rs:50-144) exists for them. The IR keeps every such expression that reads
+ * only frame constants (numbers, pi/tau/e/phi, `time`, audio.*, mouse.*, user uniforms; + - * / ^ > <, the
+ * scalar math functions) as a "derived value". game_ir_eval_derived computes them for one frame row in f32;
+ * a context created with GAME_HIP_ANIMATE_ARGS does so itself for every frame and feeds them to the kernel
+ * as extra uniforms. Without that flag the defaults are used, as the reference does. */
+uint32_t game_ir_derived_count(const game_ir* ir);
+void game_ir_eval_derived(const game_ir* ir, const float* row, float* out /* game_ir_derived_count floats */);
+
 /* Arc timeline (game-compiler/src/runtime/arc.rs:52-125, emitted by the reference as the JS function
  * arcUpdate(time, params) that its own renderer never calls): entries `target: from -> to over duration
  * [easing]` run back to back; game_ir_arc_update applies the timeline at time_s, in JS-number (double)
@@ -118,7 +128,7 @@ enum {
  *            (0 reflect, 1 wrap, 2 none), name[64]
  *   layer  : is_pipeline, stage_begin, stage_count, has_memory, decay(f32), end_state
  *            (0 Position, 1 Sdf, 2 Color), 0, 0                                   (32 bytes)
- *   stage  : builtin_id, nargs, aux(palette index), 0, then 4 x {kind, slot, lit(f32), 0}
+ *   stage  : builtin_id, nargs, aux(palette index), 0, then 4 x {kind, slot, lit(f32), derived index + 1 or 0}
  *            kind 0 = literal, 1 = user uniform slot, 2 = built-in uniform slot   (80 bytes)
  *   uniform: default(f32), name[60]                                               (64 bytes)
  *   law op : op, value(f32), fn, 0                                                (16 bytes)
@@ -135,7 +145,7 @@ int game_hip_create(const game_ir* ir, uint32_t width, uint32_t height, int devi
  * (game-compiler/src/codegen/wgsl.rs:268-540) words differently from its WebGL2 emitter (star, polygon,
  * simplex, voronoi, concentric_waves, threshold, vignette, chromatic, tonemap, scanlines, glitch, mirror,
  * repeat, curl_noise, displace, spectrum) follow the WebGPU text; flags = 0 is game_hip_create. */
-enum { GAME_HIP_SEMANTICS_WGSL = 1u };
+enum { GAME_HIP_SEMANTICS_WGSL = 1u, GAME_HIP_ANIMATE_ARGS = 2u /* see game_ir_eval_derived */ };
 int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int device, uint32_t flags,
                        game_hip_ctx** out);
 void game_hip_destroy(game_hip_ctx* ctx);

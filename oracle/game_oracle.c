@@ -194,10 +194,13 @@ typedef struct {
     float time;      /* fract(u_time / 120) * 120 */
     float aspect;    /* u_resolution.x / u_resolution.y */
     const float* row;/* this frame's uniform row: 10 built-ins then user uniforms */
+    const float* derived; /* per-frame values of expression-valued arguments, or NULL: the reference's behaviour
+                             (stages.rs:8-22 substitutes the parameter default, which kind/slot/lit hold) */
 } frame_consts;
 
 static inline float arg_value(const ir_arg* a, const frame_consts* fc)
 {
+    if (fc->derived && a->pad) return fc->derived[a->pad - 1];   /* pad = derived index + 1 */
     if (a->kind == 0) return a->lit;
     if (a->kind == 1) return fc->row[BU_COUNT + a->slot];
     return a->slot == BU_TIME ? fc->time : fc->row[a->slot];
@@ -639,6 +642,9 @@ static void* render_thread(void* p) { render_rows((const frame_job*)p); return N
  * zero). nthreads <= 1 renders on the calling thread. Returns 0, or -1 for a malformed blob. */
 int game_oracle_render_ex(const void* blob, size_t blob_len, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows,
                           const float* uniforms, const uint8_t* prev_rgba8, uint8_t* out_rgba8, int nthreads, int semantics);
+int game_oracle_render_ex2(const void* blob, size_t blob_len, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows,
+                           const float* uniforms, const uint8_t* prev_rgba8, uint8_t* out_rgba8, int nthreads, int semantics,
+                           const float* derived);
 
 int game_oracle_render(const void* blob, size_t blob_len, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows,
                        const float* uniforms, const uint8_t* prev_rgba8, uint8_t* out_rgba8, int nthreads)
@@ -650,11 +656,21 @@ int game_oracle_render(const void* blob, size_t blob_len, uint32_t w, uint32_t h
 int game_oracle_render_ex(const void* blob, size_t blob_len, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows,
                           const float* uniforms, const uint8_t* prev_rgba8, uint8_t* out_rgba8, int nthreads, int semantics)
 {
+    return game_oracle_render_ex2(blob, blob_len, w, h, row0, rows, uniforms, prev_rgba8, out_rgba8, nthreads, semantics, NULL);
+}
+
+/* derived: NULL, or this frame's value of every expression-valued stage argument, in the order the IR numbers
+ * them (the caller computes them; the stage arguments that carry an index read them instead of their default). */
+int game_oracle_render_ex2(const void* blob, size_t blob_len, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows,
+                           const float* uniforms, const uint8_t* prev_rgba8, uint8_t* out_rgba8, int nthreads, int semantics,
+                           const float* derived)
+{
     ir_view ir;
     if (ir_open(blob, blob_len, &ir) != 0 || !uniforms || !out_rgba8 || w == 0 || h == 0 || row0 + rows > h) return -1;
     frame_consts fc;
     fc.wgsl = semantics == 1;
     fc.row = uniforms;
+    fc.derived = derived;
     fc.aspect = uniforms[BU_RES_X] / uniforms[BU_RES_Y];               /* glsl.rs:55 */
     fc.time = gm_fract(uniforms[BU_TIME] / 120.0f) * 120.0f;           /* glsl.rs:56 */
     if (nthreads < 1) nthreads = 1;

@@ -43,6 +43,8 @@ class Oracle:
                                          c.c_void_p, c.c_void_p, c.c_void_p, c.c_int]
         L.game_oracle_render_ex.restype = c.c_int
         L.game_oracle_render_ex.argtypes = L.game_oracle_render.argtypes + [c.c_int]
+        L.game_oracle_render_ex2.restype = c.c_int
+        L.game_oracle_render_ex2.argtypes = L.game_oracle_render.argtypes + [c.c_int, c.c_void_p]
         L.game_oracle_gravity.restype = c.c_int
         L.game_oracle_gravity.argtypes = [c.c_void_p, c.c_size_t, c.c_uint32, c.c_void_p, c.c_float, c.c_uint32,
                                           c.POINTER(c.c_float), c.c_int]
@@ -57,24 +59,29 @@ class Oracle:
         L.game_oracle_fbm2.argtypes = [c.c_float, c.c_float, c.c_int, c.c_float, c.c_float]
         self.L = L
 
-    def render(self, blob, w, h, row, prev=None, row0=0, rows=None, threads=8, semantics="glsl"):
+    def render(self, blob, w, h, row, prev=None, row0=0, rows=None, threads=8, semantics="glsl", derived=None):
         rows = h if rows is None else rows
         row = np.ascontiguousarray(row, dtype=np.float32)
         out = np.zeros((rows, w, 4), dtype=np.uint8)
         if prev is not None:
             prev = np.ascontiguousarray(prev, dtype=np.uint8)
             assert prev.shape == out.shape
-        rc = self.L.game_oracle_render_ex(blob, len(blob), w, h, row0, rows, row.ctypes.data,
-                                          None if prev is None else prev.ctypes.data, out.ctypes.data, threads,
-                                          {"glsl": 0, "wgsl": 1}[semantics])
+        if derived is not None:
+            derived = np.ascontiguousarray(derived, dtype=np.float32)
+        rc = self.L.game_oracle_render_ex2(blob, len(blob), w, h, row0, rows, row.ctypes.data,
+                                           None if prev is None else prev.ctypes.data, out.ctypes.data, threads,
+                                           {"glsl": 0, "wgsl": 1}[semantics],
+                                           None if derived is None or derived.size == 0 else derived.ctypes.data)
         assert rc == 0, "oracle rejected the IR blob or arguments"
         return out
 
-    def render_sequence(self, blob, w, h, rows_table, uses_memory, row0=0, rows=None, threads=8, semantics="glsl"):
+    def render_sequence(self, blob, w, h, rows_table, uses_memory, row0=0, rows=None, threads=8, semantics="glsl",
+                        derived=None):
+        """derived: None, or one row of expression-argument values per frame."""
         frames, prev = [], None
-        for r in rows_table:
+        for k, r in enumerate(rows_table):
             f = self.render(blob, w, h, r, prev=prev if uses_memory else None, row0=row0, rows=rows, threads=threads,
-                            semantics=semantics)
+                            semantics=semantics, derived=None if derived is None else derived[k])
             frames.append(f)
             prev = f
         return np.stack(frames)

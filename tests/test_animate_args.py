@@ -1,0 +1,147 @@
+"""Expression-valued stage arguments. The reference's stage emitters replace any argument that is not a number,
+an identifier or a dotted name by the parameter's default (game-compiler/src/codegen/stages.rs:8-22), although
+its expression compiler (codegen/expr.rs:50-144) handles them; that stays the default behaviour here. With the
+animate flag the host evaluates those expressions once per frame and the kernel reads the values as uniforms.
+The checker for the values is a Python statement of each expression (float64 = JS numbers, one rounding to f32)."""
+import math
+
+import numpy as np
+import pytest
+
+SRC = '''cinematic "spin" {
+  layer a {
+    fn: rotate(time * 1.5) | star(5.0, 0.3 + sin(time * 2.0) * 0.05, 0.12) | glow(1.0 + audio.bass * 3.0) | tint(0.9, 0.4 + 0.3 * cos(time), mix(0.1, 0.6, audio.beat))
+  }
+  layer b {
+    fn: translate(mouse.x - 0.5, -(mouse.y - 0.5)) | circle(size * 0.5 + 0.05) | glow(2.0 ^ 1.5) | tint(0.2, 0.5, 1.0)
+    size: 0.3
+  }
+}'''
+
+F = np.float32
+
+
+def f32(x):
+    return float(F(x))
+
+
+def wrapped_time(t):
+    q = F(t) / F(120.0)
+    return float((q - np.floor(q)) * F(120.0))
+
+
+def expected(row):
+    """The eight expressions of SRC in source order (`2.0 ^ 1.5` is folded to a number by the front end); literals pass through f32 like every literal of the language."""
+    t = wrapped_time(row[0])
+    bass, beat, mx, my, size = (float(row[1]), float(row[5]), float(row[8]), float(row[9]), float(row[10]))
+    return np.array([
+        t * f32(1.5),
+        f32(0.3) + math.sin(t * f32(2.0)) * f32(0.05),
+        f32(1.0) + bass * f32(3.0),
+        f32(0.4) + f32(0.3) * math.cos(t),
+        f32(0.1) * (1.0 - beat) + f32(0.6) * beat,
+        mx - f32(0.5),
+        -(my - f32(0.5)),
+        size * f32(0.5) + f32(0.05),
+    ], dtype=np.float64).astype(np.float32)
+
+
+def test_derived_programs_are_kept_in_source_order(game):
+    cin = game.compile(SRC).cinematics[0]
+    assert cin.derived_count == 8
+    ir = cin.ir
+    assert ir["derived"][0] == "(time * 1.500000)" and ir["derived"][2] == "(1.000000 + (audio.bass * 3.000000))"
+    stages = [st for layer in ir["layers"] for st in layer["stages"]]
+    idx = [a["derived"] for st in stages for a in st["args"]]
+    assert [i for i in idx if i >= 0] == list(range(8))
+    # the default every such argument keeps (what the reference's emitters substitute) is still in the IR
+    rot = stages[0]["args"][0]
+    assert rot["kind"] == "lit" and rot["text"] == "0.000000"
+
+
+def test_derived_values_follow_the_expressions(game):
+    cin = game.compile(SRC).cinematics[0]
+    times = [0.0, 1.0 / 60.0, 0.5, 3.25, 119.99, 130.0, 1000.5]
+    rows = cin.uniform_rows(times, 64, 36, audio={"bass": 0.25, "beat": 0.75}, user={"size": 0.4})
+    rows[:, 8] = np.linspace(0.0, 1.0, len(times), dtype=np.float32)    # mouse.x
+    rows[:, 9] = np.linspace(1.0, 0.0, len(times), dtype=np.float32)    # mouse.y
+    got = cin.eval_derived(rows)
+    want = np.stack([expected(r) for r in rows])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("src,n", [
+    ('cinematic "a" { layer x { fn: circle(nope * 2.0) | glow(1.0) } }', 0),          # unknown name: not a frame constant
+    ('cinematic "a" { layer x { fn: circle(0.2) | palette(time + 1.0) } }', 0),   # palette names are text
+    ('cinematic "a" { layer x { fn: fbm(2.0, 3.0 + time, 0.5, 2.0) | glow(1.0) } }', 0),      # octave count stays compile-time
+    ('cinematic "a" { layer x { fn: fbm(2.0 * time, 4.0, 0.5, 2.0) | glow(1.0) } }', 1),
+    ('cinematic "a" { layer x { fn: circle(radius: 0.1 + mouse.x) | glow(1.0) } }', 1),         # named argument
+    ('cinematic "a" { layer x { fn: circle(0.2) | glow(time) } }', 0),                         # plain identifiers are uniforms already
+    ('cinematic "a" { layer x { fn: circle(nofunc(time)) | glow(1.0) } }', 0),
+])
+def test_which_arguments_become_programs(game, src, n):
+    assert game.compile(src).cinematics[0].derived_count == n
+
+
+def test_default_behaviour_is_the_references(game, oracle):
+    """Without the flag an expression renders as the parameter default: same frame as the source with defaults."""
+    a = game.compile('cinematic "a" { layer x { fn: rotate(time * 1.5) | star(5.0, 0.3 + audio.bass * 0.1, 0.12) | glow(2.0) } }').cinematics[0]
+    b = game.compile('cinematic "a" { layer x { fn: rotate(0.0) | star(5.0, 0.3, 0.12) | glow(2.0) } }').cinematics[0]
+    row = a.uniform_rows([1.25], 48, 27, audio={"bass": 1.0})[0]
+    assert np.array_equal(oracle.render(a.blob, 48, 27, row), oracle.render(b.blob, 48, 27, row))
+    # and with the values passed in, the oracle renders what the same values do as plain uniforms
+    d = a.eval_derived(row[None])[0]
+    assert np.array_equal(d, np.array([1.875, float(np.float32(0.3)) + float(np.float32(0.1))], dtype=np.float32))
+    c = game.compile('cinematic "a" { layer x { fn: rotate(ang) | star(5.0, rad, 0.12) | glow(2.0) } }').cinematics[0]
+    crow = c.uniform_rows([1.25], 48, 27, audio={"bass": 1.0}, user={"ang": float(d[0]), "rad": float(d[1])})[0]
+    animated = oracle.render(a.blob, 48, 27, row, derived=d)
+    assert np.array_equal(animated, oracle.render(c.blob, 48, 27, crow))
+    assert not np.array_equal(animated, oracle.render(a.blob, 48, 27, row))
+
+
+def test_animate_kernels_compile_for_gfx950(game):
+    cin = game.compile(SRC).cinematics[0]
+    assert cin.compile_only(animate=True) > 0
+    assert cin.compile_only(semantics="wgsl", animate=True) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("semantics", ["glsl", "wgsl"])
+def test_gpu_animated_arguments_match_oracle(game, oracle, semantics):
+    cin = game.compile(SRC).cinematics[0]
+    w, h = 160, 90
+    times = [0.0, 0.4, 2.5, 130.0]
+    rows = cin.uniform_rows(times, w, h, audio={"bass": 0.25, "beat": 0.75}, user={"size": 0.4})
+    rows[:, 8] = 0.7
+    rows[:, 9] = 0.35
+    derived = np.stack([expected(r) for r in rows])
+    r = cin.renderer(w, h, semantics=semantics, animate=True)
+    got = r.render(rows)
+    r.close()
+    want = oracle.render_sequence(cin.blob, w, h, rows, False, semantics=semantics, derived=derived)
+    assert np.array_equal(got, want)
+    # the flag changes the picture: the default-argument frames differ
+    still = oracle.render_sequence(cin.blob, w, h, rows, False, semantics=semantics)
+    assert not np.array_equal(want, still)
+    # and a context without the flag renders exactly those default-argument frames
+    r = cin.renderer(w, h, semantics=semantics)
+    got = r.render(rows)
+    r.close()
+    assert np.array_equal(got, still)
+
+
+@pytest.mark.gpu
+def test_gpu_animated_memory_sequence(game, oracle):
+    src = '''cinematic "trail" {
+      layer orb memory: 0.9 { fn: translate(sin(time * 3.0) * 0.5, cos(time * 2.0) * 0.3) | circle(0.08 + audio.bass * 0.1) | glow(2.5) | tint(1.0, 0.6, 0.2) }
+    }'''
+    cin = game.compile(src).cinematics[0]
+    assert cin.uses_memory and cin.derived_count == 3
+    w, h = 128, 72
+    rows = cin.uniform_rows([k / 30 for k in range(6)], w, h, audio={"bass": 0.5})
+    derived = cin.eval_derived(rows)
+    r = cin.renderer(w, h, animate=True)
+    got = r.render(rows)
+    r.close()
+    want = oracle.render_sequence(cin.blob, w, h, rows, True, derived=derived)
+    assert np.array_equal(got, want)
