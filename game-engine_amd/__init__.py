@@ -60,6 +60,10 @@ def _load():
         "game_ir_default_uniforms": (None, [vp, f32, u32, u32, vp]),
         "game_ir_derived_count": (u32, [vp]),
         "game_ir_eval_derived": (None, [vp, vp, vp]),
+        "game_animator_create": (c.c_int, [vp, c.c_double, c.POINTER(vp)]),
+        "game_animator_destroy": (None, [vp]),
+        "game_animator_reset": (None, [vp]),
+        "game_animator_step": (c.c_int, [vp, c.c_double, c.c_double, vp, u32, vp, vp, u32]),
         "game_ir_arc_count": (u32, [vp]),
         "game_ir_arc_update": (None, [vp, c.c_double, vp]),
         "game_hip_device_count": (c.c_int, [c.POINTER(c.c_int)]),
@@ -188,6 +192,10 @@ class Cinematic:
             lib.game_ir_eval_derived(self._h, rows[k].ctypes.data, out[k].ctypes.data)
         return out
 
+    def animator(self, fps=60.0):
+        """Stateful host-side animation of the user uniforms: arcs, `~` modulation, temporal operators, resonance."""
+        return Animator(self, fps)
+
     def compile_only(self, semantics="glsl", animate=False):
         """hiprtc-compiles the generated kernels for gfx950 without a device; returns code bytes."""
         n = ctypes.c_size_t()
@@ -289,6 +297,50 @@ def pinned_array(shape):
     buf = (ctypes.c_ubyte * n).from_address(ptr)
     weakref.finalize(buf, lib.game_hip_host_free, ptr)
     return np.frombuffer(buf, dtype=np.uint8).reshape(shape)
+
+
+class Animator:
+    """game_animator: call step() once per frame, in frame order; the row's user uniforms are updated in place."""
+    ARCS, MODULATION, RESONANCE = 1, 2, 4
+
+    def __init__(self, cinematic, fps=60.0):
+        h_ = ctypes.c_void_p()
+        _check(lib.game_animator_create(cinematic._h, float(fps), ctypes.byref(h_)))
+        self._h = h_
+        self.fps = float(fps) if fps else 60.0
+
+    def step(self, time_s, dt, row, what=0, signals=None):
+        assert row.dtype == np.float32 and row.flags["C_CONTIGUOUS"]
+        signals = signals or {}
+        n = len(signals)
+        names = (ctypes.c_char_p * max(n, 1))(*[k.encode() for k in signals])
+        values = (ctypes.c_double * max(n, 1))(*[float(v) for v in signals.values()])
+        _check(lib.game_animator_step(self._h, float(time_s), float(dt), row.ctypes.data, what, names, values, n))
+        return row
+
+    def apply(self, rows, times, what=0, signals=None):
+        """Steps through (n, frame_floats) rows in order; dt is the time since the previous frame (1/fps for the first).
+        signals: None, or one dict of named signal values per frame."""
+        prev = None
+        for k, t in enumerate(times):
+            dt = 1.0 / self.fps if prev is None else float(t) - prev
+            self.step(t, dt, rows[k], what, None if signals is None else signals[k])
+            prev = float(t)
+        return rows
+
+    def reset(self):
+        lib.game_animator_reset(self._h)
+
+    def close(self):
+        if self._h:
+            lib.game_animator_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Renderer:

@@ -11,7 +11,8 @@
 //                                        or PREFIX_00000.png (8-bit RGBA, stored deflate blocks) with --png;
 //                                        the cinematic's arc timeline (runtime/arc.rs) drives its parameters unless
 //                                        --no-arcs; --animate evaluates expression-valued stage arguments per frame
-//                                        (the reference's emitters use the parameter defaults); --semantics wgsl renders the builtins as the reference's WebGPU emitter
+//                                        (the reference's emitters use the parameter defaults) and runs `~` modulation
+//                                        and the temporal operators of the parameters on the host; --semantics wgsl renders the builtins as the reference's WebGPU emitter
 //                                        words them (wgsl.rs:268-540) instead of its WebGL2 emitter
 //   game compare A B [--threshold T]     two frames (.ppm or .png written by this tool): share of pixels whose
 //                                        channels all differ by <= T (the measure of snapshot.rs:240-258,
@@ -339,6 +340,12 @@ int cmd_render(const Args& a)
             host.p = (uint8_t*)game_hip_host_alloc((size_t)batch * a.w * a.h * 4);
             if (!host.p) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
         }
+        // --animate: modulation, temporal operators and resonance of the parameters run on the host, frame by frame
+        struct Anim {
+            game_animator* p = nullptr;
+            ~Anim() { game_animator_destroy(p); }
+        } anim;
+        if (a.animate && game_animator_create(ir, a.fps, &anim.p) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
         auto t0 = std::chrono::steady_clock::now();
         double device_ms = 0;
         bool ok = true;
@@ -347,7 +354,8 @@ int cmd_render(const Args& a)
             for (uint32_t k = 0; k < n; ++k) {
                 float* row = rows.data() + (size_t)k * nf;
                 game_ir_default_uniforms(ir, (float)((done + k) / a.fps), a.w, a.h, row);
-                if (a.arcs) game_ir_arc_update(ir, (done + k) / a.fps, row);   // the cinematic's own timeline animates its parameters
+                if (anim.p) game_animator_step(anim.p, (done + k) / a.fps, 1.0 / a.fps, row, (a.arcs ? 1u : 0u) | 6u, nullptr, nullptr, 0);
+                else if (a.arcs) game_ir_arc_update(ir, (done + k) / a.fps, row);   // the cinematic's own timeline animates its parameters
             }
             if (game_hip_render(ctx, rows.data(), n, host.empty() ? nullptr : host.data()) != GAME_OK) { ok = false; break; }
             float ms = 0; uint32_t launches = 0;

@@ -133,6 +133,32 @@ void game_ir_eval_derived(const game_ir* ir, const float* row, float* out)
     if (ir && row && out) eval_derived(*ir->ir, row, out);
 }
 
+struct game_animator { Ir ir; Animator a; };   // owns a copy: the program may be freed first
+
+int game_animator_create(const game_ir* ir, double fps, game_animator** out)
+{
+    if (!ir || !out) return set_error(GAME_E_ARGUMENT, "game_animator_create: null argument");
+    if (!(fps >= 0.0) || fps > 1.0e6) return set_error(GAME_E_ARGUMENT, "game_animator_create: fps must be 0 (= 60) or a positive rate");
+    auto* an = new game_animator;
+    an->ir = *ir->ir;
+    an->a.init(an->ir, fps);
+    *out = an;
+    return GAME_OK;
+}
+
+void game_animator_destroy(game_animator* an) { delete an; }
+void game_animator_reset(game_animator* an) { if (an) an->a.reset(); }
+
+int game_animator_step(game_animator* an, double time_s, double dt, float* row, uint32_t what,
+                       const char* const* signal_names, const double* signal_values, uint32_t nsignals)
+{
+    if (!an || !row) return set_error(GAME_E_ARGUMENT, "game_animator_step: null argument");
+    if (what > 7u) return set_error(GAME_E_ARGUMENT, "game_animator_step: unknown bit in `what`");
+    if (nsignals && (!signal_names || !signal_values)) return set_error(GAME_E_ARGUMENT, "game_animator_step: signals without names or values");
+    an->a.step(time_s, dt, row, what, signal_names, signal_values, nsignals);
+    return GAME_OK;
+}
+
 uint32_t game_ir_arc_count(const game_ir* ir) { return ir ? (uint32_t)ir->ir->arcs.size() : 0; }
 
 void game_ir_arc_update(const game_ir* ir, double time_s, float* row)

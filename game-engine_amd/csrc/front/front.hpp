@@ -252,6 +252,14 @@ struct IrArc {
 // pushes slot `fn` of the frame row, where slot 0 is the wrapped time the shader calls `time`).
 struct IrDerived { std::vector<IrLawOp> prog; std::string text; };
 
+// Host-side animation of one user uniform: `name: base ~ modulation <> 50ms >> 200ms .. [0, 1]`
+// (temporal.rs:90-176). The modulation is a frame-level program (prog empty: none, or it reads something that
+// is not a frame constant); ops run left to right on the modulated value.
+struct IrTemporal { uint8_t kind = 0; double secs = 0.0, lo = 0.0, hi = 0.0; };   // kind: TemporalOp::Kind
+struct IrParamAnim { int idx = -1; std::string name; std::vector<IrLawOp> mod; std::string mod_text; std::vector<IrTemporal> ops; };
+// `source -> target.field * weight` (resonance.rs:32-61): params[idx] += signal(source) * weight * dt
+struct IrResonance { int idx = -1; std::string source, target; double weight = 0.0; };
+
 struct Ir {
     std::string name;
     bool multi_layer = false;     // cinematic.layers.len() > 1, params layers included (glsl.rs:66)
@@ -263,6 +271,24 @@ struct Ir {
     bool uses_memory = false;
     std::vector<IrArc> arcs;
     std::vector<IrDerived> derived;
+    std::vector<IrParamAnim> anims;
+    std::vector<IrResonance> resonances;
+};
+
+// Value of a frame-level program over one frame row, binary64. wrap_time: `time` is the shader's wrapped f32
+// time (stage arguments); otherwise the raw u_time of the row (host-side modulation, as JS sees it).
+double eval_frame_prog(const std::vector<IrLawOp>& prog, const float* row, bool wrap_time);
+
+// Per-context state of the temporal operators (the JS classes of temporal.rs:31-82) plus the frame step that
+// applies arcs, modulation + temporal operators and resonance to the user uniforms of a frame row.
+struct Animator {
+    struct OpState { std::vector<float> ring; size_t head = 0; bool has_value = false; double value = 0.0, prev = 0.0, envelope = 0.0; };
+    const Ir* ir = nullptr;
+    double fps = 60.0;
+    std::vector<std::vector<OpState>> state;   // [anim][op]
+    void init(const Ir& ir_, double fps_);
+    void reset();
+    void step(double time_s, double dt, float* row, uint32_t what, const char* const* names, const double* values, uint32_t nsignals);
 };
 
 // Values of Ir::derived for one frame row (10 built-ins + user uniforms), f32 arithmetic.

@@ -180,9 +180,8 @@ bool lower_frame_expr(const Expr& e, const std::map<std::string, uint32_t>& uslo
 }  // namespace
 
 // Arithmetic is binary64 with the C library's functions, as a JavaScript host would compute a uniform
-// before handing it to the shader (the same convention as the arc timeline); `time` is the f32 value the
-// shader itself sees (u_time wrapped to [0,120), glsl.rs:56); each result is rounded to f32 once.
-void eval_derived(const Ir& ir, const float* row, float* out)
+// before handing it to the shader (the same convention as the arc timeline).
+double eval_frame_prog(const std::vector<IrLawOp>& prog, const float* row, bool wrap_time)
 {
     auto call = [](uint32_t fn, double a, double b, double c) -> double {
         switch (fn) {
@@ -198,37 +197,135 @@ void eval_derived(const Ir& ir, const float* row, float* out)
         default: return 0.0;
         }
     };
-    for (size_t d = 0; d < ir.derived.size(); ++d) {
-        double st[64];
-        int sp = 0;
-        for (const IrLawOp& o : ir.derived[d].prog) {
-            switch (o.op) {
-            case LAW_NUM: st[sp++] = (double)o.val; break;
-            case LAW_UNIFORM: {
-                float v = row[o.fn];
-                if (o.fn == BU_TIME) {
-                    float q = v / 120.0f, f = q - floorf(q);
-                    if (f == f && !(f < 1.0f)) f = 0x1.fffffep-1f;
-                    v = f * 120.0f;
-                }
-                st[sp++] = (double)v;
-                break;
+    double st[64];
+    int sp = 0;
+    for (const IrLawOp& o : prog) {
+        switch (o.op) {
+        case LAW_NUM: st[sp++] = (double)o.val; break;
+        case LAW_UNIFORM: {
+            float v = row[o.fn];
+            if (o.fn == BU_TIME && wrap_time) {   // glsl.rs:56
+                float q = v / 120.0f, f = q - floorf(q);
+                if (f == f && !(f < 1.0f)) f = 0x1.fffffep-1f;
+                v = f * 120.0f;
             }
-            case LAW_ADD: sp--; st[sp - 1] = st[sp - 1] + st[sp]; break;
-            case LAW_SUB: sp--; st[sp - 1] = st[sp - 1] - st[sp]; break;
-            case LAW_MUL: sp--; st[sp - 1] = st[sp - 1] * st[sp]; break;
-            case LAW_DIV: sp--; st[sp - 1] = st[sp - 1] / st[sp]; break;
-            case LAW_POW: sp--; st[sp - 1] = pow(st[sp - 1], st[sp]); break;
-            case LAW_GT: sp--; st[sp - 1] = st[sp - 1] > st[sp] ? 1.0 : 0.0; break;
-            case LAW_LT: sp--; st[sp - 1] = st[sp - 1] < st[sp] ? 1.0 : 0.0; break;
-            case LAW_NEG: st[sp - 1] = -st[sp - 1]; break;
-            case LAW_CALL1: st[sp - 1] = call(o.fn, st[sp - 1], 0.0, 0.0); break;
-            case LAW_CALL2: sp--; st[sp - 1] = call(o.fn, st[sp - 1], st[sp], 0.0); break;
-            case LAW_CALL3: sp -= 2; st[sp - 1] = call(o.fn, st[sp - 1], st[sp], st[sp + 1]); break;
-            default: break;
+            st[sp++] = (double)v;
+            break;
+        }
+        case LAW_ADD: sp--; st[sp - 1] = st[sp - 1] + st[sp]; break;
+        case LAW_SUB: sp--; st[sp - 1] = st[sp - 1] - st[sp]; break;
+        case LAW_MUL: sp--; st[sp - 1] = st[sp - 1] * st[sp]; break;
+        case LAW_DIV: sp--; st[sp - 1] = st[sp - 1] / st[sp]; break;
+        case LAW_POW: sp--; st[sp - 1] = pow(st[sp - 1], st[sp]); break;
+        case LAW_GT: sp--; st[sp - 1] = st[sp - 1] > st[sp] ? 1.0 : 0.0; break;
+        case LAW_LT: sp--; st[sp - 1] = st[sp - 1] < st[sp] ? 1.0 : 0.0; break;
+        case LAW_NEG: st[sp - 1] = -st[sp - 1]; break;
+        case LAW_CALL1: st[sp - 1] = call(o.fn, st[sp - 1], 0.0, 0.0); break;
+        case LAW_CALL2: sp--; st[sp - 1] = call(o.fn, st[sp - 1], st[sp], 0.0); break;
+        case LAW_CALL3: sp -= 2; st[sp - 1] = call(o.fn, st[sp - 1], st[sp], st[sp + 1]); break;
+        default: break;
+        }
+    }
+    return sp >= 1 ? st[0] : 0.0;
+}
+
+// Stage-argument values: `time` is the f32 value the shader itself sees (u_time wrapped to [0,120));
+// each result is rounded to f32 once.
+void eval_derived(const Ir& ir, const float* row, float* out)
+{
+    for (size_t d = 0; d < ir.derived.size(); ++d) out[d] = (float)eval_frame_prog(ir.derived[d].prog, row, true);
+}
+
+// ── temporal operators, modulation, resonance ────────────────────────────
+void Animator::init(const Ir& ir_, double fps_)
+{
+    ir = &ir_;
+    fps = fps_ > 0.0 ? fps_ : 60.0;   // the JS classes default to 60 (temporal.rs:33,52,69)
+    reset();
+}
+
+void Animator::reset()
+{
+    state.assign(ir->anims.size(), {});
+    for (size_t i = 0; i < ir->anims.size(); ++i) {
+        state[i].resize(ir->anims[i].ops.size());
+        for (size_t k = 0; k < ir->anims[i].ops.size(); ++k) {
+            const IrTemporal& op = ir->anims[i].ops[k];
+            if (op.kind == TemporalOp::Delay) {   // GameRingBuffer: max(1, ceil(duration * fps)) zeroed f32 slots
+                double n = std::ceil(op.secs * fps);
+                if (!(n >= 1.0)) n = 1.0;
+                if (n > 16777216.0) n = 16777216.0;
+                state[i][k].ring.assign((size_t)n, 0.0f);
             }
         }
-        out[d] = (float)st[0];
+    }
+}
+
+void Animator::step(double time_s, double dt, float* row, uint32_t what, const char* const* names, const double* values, uint32_t nsignals)
+{
+    if (what == 0) what = 7u;
+    float* user = row + BU_COUNT;
+    if ((what & 1u) && !ir->arcs.empty()) {
+        std::vector<double> params(ir->uniforms.size());
+        for (size_t i = 0; i < params.size(); ++i) params[i] = user[i];
+        arc_update(*ir, time_s, params.data());
+        for (size_t i = 0; i < params.size(); ++i) user[i] = (float)params[i];
+    }
+    if (what & 2u) {
+        // every modulation reads the row as it stood before this pass, so the order of the parameters does not matter
+        std::vector<double> mods(ir->anims.size(), 0.0);
+        for (size_t i = 0; i < ir->anims.size(); ++i)
+            if (!ir->anims[i].mod.empty()) mods[i] = eval_frame_prog(ir->anims[i].mod, row, false);
+        for (size_t i = 0; i < ir->anims.size(); ++i) {
+            const IrParamAnim& pa = ir->anims[i];
+            if (pa.idx < 0) continue;
+            double v = (double)user[pa.idx] + mods[i];
+            for (size_t k = 0; k < pa.ops.size(); ++k) {
+                const IrTemporal& op = pa.ops[k];
+                OpState& s = state[i][k];
+                switch (op.kind) {
+                case TemporalOp::Delay:        // push, then read the slot the head now points at (temporal.rs:38-44)
+                    s.ring[s.head] = (float)v;
+                    s.head = (s.head + 1) % s.ring.size();
+                    v = (double)s.ring[s.head];
+                    break;
+                case TemporalOp::Smooth: {     // temporal.rs:52-61
+                    double samples = op.secs * fps;
+                    if (!(samples >= 1.0)) samples = 1.0;
+                    const double alpha = 2.0 / (samples + 1.0);
+                    if (!s.has_value) { s.has_value = true; s.value = v; }
+                    else s.value += alpha * (v - s.value);
+                    v = s.value;
+                    break;
+                }
+                case TemporalOp::Trigger: {    // temporal.rs:69-80
+                    double n = op.secs * fps;
+                    if (!(n >= 1.0)) n = 1.0;
+                    const double delta = v - s.prev;
+                    s.prev = v;
+                    if (delta > 0.01) s.envelope = 1.0;
+                    else { s.envelope -= 1.0 / n; if (!(s.envelope > 0.0)) s.envelope = 0.0; }
+                    v = s.envelope;
+                    break;
+                }
+                default:                       // Range: Math.min(Math.max(v, lo), hi)
+                    v = v > op.lo ? v : op.lo;
+                    v = v < op.hi ? v : op.hi;
+                    break;
+                }
+            }
+            user[pa.idx] = (float)v;
+        }
+    }
+    if (what & 4u) {
+        for (const IrResonance& r : ir->resonances) {
+            if (r.idx < 0) continue;
+            double sig = 0.0;                  // signals[source] || 0
+            for (uint32_t i = 0; i < nsignals; ++i)
+                if (names && values && names[i] && r.source == names[i]) { sig = values[i]; break; }
+            if (sig != sig) sig = 0.0;
+            user[r.idx] = (float)((double)user[r.idx] + sig * r.weight * dt);
+        }
     }
 }
 
@@ -342,6 +439,49 @@ Ir lower_cinematic(const Cinematic& c)
             if (!eval_js_const(e.from, a.from) || !eval_js_const(e.to, a.to)) a.idx = -1;
             ir.arcs.push_back(std::move(a));
             cursor += ir.arcs.back().dur;
+        }
+    }
+
+    // modulation and temporal operators of layer parameters (Params-style layers as codegen/mod.rs:122-135 collects
+    // them, and the inline parameters of pipeline layers, which are uniforms by codegen/mod.rs:75-87)
+    auto dur_secs = [](const Duration& d) { return d.kind == DurKind::Seconds ? d.v : d.kind == DurKind::Millis ? d.v / 1000.0 : (double)d.bars * 2.0; };
+    auto add_anim = [&](const Param& p) {
+        if (!p.has_mod && p.temporal.empty()) return;
+        IrParamAnim pa;
+        pa.name = p.name;
+        auto it = uslot.find(p.name);
+        if (it != uslot.end()) pa.idx = (int)it->second;
+        if (p.has_mod) {
+            if (!lower_frame_expr(p.modulation, uslot, pa.mod) || pa.mod.size() >= 48) pa.mod.clear();
+            pa.mod_text = expr_source_text(p.modulation);
+        }
+        for (const TemporalOp& t : p.temporal) {
+            IrTemporal o;
+            o.kind = (uint8_t)t.kind;
+            if (t.kind == TemporalOp::Range) {   // temporal.rs:21-28: numbers pass, anything else is not a number here
+                if (!eval_js_const(t.lo, o.lo)) o.lo = 0.0;
+                if (!eval_js_const(t.hi, o.hi)) o.hi = 0.0;
+            } else {
+                o.secs = dur_secs(t.dur);
+            }
+            pa.ops.push_back(o);
+        }
+        ir.anims.push_back(std::move(pa));
+    };
+    for (const Layer& l : c.layers) {
+        if (!l.is_pipeline) for (const Param& p : l.params) add_anim(p);
+        for (const Param& p : l.opts) add_anim(p);
+    }
+    // resonance (resonance.rs:32-61): the uniform is "target_field", else "field"
+    for (const ResonateBlock& blk : c.resonates) {
+        for (const ResonateEntry& e : blk.entries) {
+            IrResonance r;
+            r.source = e.source;
+            r.target = e.target + "." + e.field;
+            for (size_t i = 0; i < ir.uniforms.size() && r.idx < 0; ++i) if (ir.uniforms[i].name == e.target + "_" + e.field) r.idx = (int)i;
+            for (size_t i = 0; i < ir.uniforms.size() && r.idx < 0; ++i) if (ir.uniforms[i].name == e.field) r.idx = (int)i;
+            if (!eval_js_const(e.weight, r.weight)) r.idx = -1;
+            ir.resonances.push_back(std::move(r));
         }
     }
 
@@ -588,6 +728,24 @@ std::string ir_to_json(const Ir& ir)
     }
     j += ",\"derived\":[";
     for (size_t i = 0; i < ir.derived.size(); ++i) j += (i ? ",\"" : "\"") + json_escape(ir.derived[i].text) + "\"";
+    j += "]";
+    j += ",\"anims\":[";
+    for (size_t i = 0; i < ir.anims.size(); ++i) {
+        const IrParamAnim& pa = ir.anims[i];
+        static const char* const kinds[] = {"delay", "smooth", "trigger", "range"};
+        j += std::string(i ? "," : "") + "{\"name\":\"" + json_escape(pa.name) + "\",\"idx\":" + std::to_string(pa.idx) +
+             ",\"modulation\":" + (pa.mod_text.empty() ? std::string("null") : "\"" + json_escape(pa.mod_text) + "\"") +
+             ",\"evaluated\":" + (pa.mod.empty() ? "false" : "true") + ",\"ops\":[";
+        for (size_t k = 0; k < pa.ops.size(); ++k)
+            j += std::string(k ? "," : "") + "{\"kind\":\"" + kinds[pa.ops[k].kind & 3] + "\",\"secs\":" + fmt_f64_display(pa.ops[k].secs) +
+                 ",\"lo\":" + fmt_f64_display(pa.ops[k].lo) + ",\"hi\":" + fmt_f64_display(pa.ops[k].hi) + "}";
+        j += "]}";
+    }
+    j += "],\"resonances\":[";
+    for (size_t i = 0; i < ir.resonances.size(); ++i)
+        j += std::string(i ? "," : "") + "{\"source\":\"" + json_escape(ir.resonances[i].source) + "\",\"target\":\"" +
+             json_escape(ir.resonances[i].target) + "\",\"idx\":" + std::to_string(ir.resonances[i].idx) + ",\"weight\":" +
+             fmt_f64_display(ir.resonances[i].weight) + "}";
     j += "]";
     j += ",\"arcs\":[";
     for (size_t i = 0; i < ir.arcs.size(); ++i) {

@@ -104,6 +104,25 @@ void game_ir_default_uniforms(const game_ir* ir, float time_s, uint32_t w, uint3
 uint32_t game_ir_derived_count(const game_ir* ir);
 void game_ir_eval_derived(const game_ir* ir, const float* row, float* out /* game_ir_derived_count floats */);
 
+/* Host-side animation of the user uniforms, one call per frame, in frame order. The reference emits this as
+ * JavaScript that nothing calls: the modulation `base ~ expr` (LANGUAGE.md section 8: the value of `expr` is
+ * added to the base every frame), the temporal operators `>>` `<>` `!!` `..` as the classes GameRingBuffer,
+ * GameEMAFilter and GameEdgeDetector (game-compiler/src/codegen/temporal.rs:31-82, applied left to right as
+ * :130-172), `resonanceUpdate(params, signals, dt)` (codegen/resonance.rs:20-65) and `arcUpdate(time, params)`
+ * (runtime/arc.rs:109-122). game_animator_step applies, in this order and to the user uniforms of `row`
+ * (game_ir_frame_floats floats, in/out): bit 0 of `what` the arc timeline at time_s; bit 1 modulation (over
+ * the row's own time/audio/mouse/user values; `time` here is the raw u_time, as the JS sees it) followed by
+ * the parameter's temporal operators; bit 2 resonance with the caller's named signals. what = 0 means all
+ * three. Arithmetic is binary64 (JS numbers), ring buffers hold f32 (Float32Array), results are stored as
+ * f32. fps sizes the temporal operators (0 = 60, the classes' default). The animator keeps the operators'
+ * state between calls; game_animator_reset returns it to the first frame. */
+typedef struct game_animator game_animator;
+int game_animator_create(const game_ir* ir, double fps, game_animator** out);
+void game_animator_destroy(game_animator* an);
+void game_animator_reset(game_animator* an);
+int game_animator_step(game_animator* an, double time_s, double dt, float* row, uint32_t what,
+                       const char* const* signal_names, const double* signal_values, uint32_t nsignals);
+
 /* Arc timeline (game-compiler/src/runtime/arc.rs:52-125, emitted by the reference as the JS function
  * arcUpdate(time, params) that its own renderer never calls): entries `target: from -> to over duration
  * [easing]` run back to back; game_ir_arc_update applies the timeline at time_s, in JS-number (double)

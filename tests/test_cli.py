@@ -118,3 +118,32 @@ def test_render_writes_frames_equal_to_the_library(tmp_path, game):
         assert data.startswith(header)
         rgb = np.frombuffer(data[len(header):], dtype=np.uint8).reshape(64, 96, 3)
         assert np.array_equal(rgb, want[k][..., :3])
+
+
+@pytest.mark.gpu
+def test_render_animate_runs_modulation_and_expression_arguments(tmp_path, game):
+    src = '''cinematic "pulse" {
+      layer orb { fn: rotate(time * 2.0) | star(5.0, radius, 0.1) | glow(2.0) | tint(1.0, 0.7, 0.3)
+        radius: 0.25 ~ sin(time * 6.0) * 0.1 <> 100ms }
+    }'''
+    f = tmp_path / "p.game"
+    f.write_text(src)
+    out = str(tmp_path / "a")
+    r = run("render", str(f), "--hip", "--animate", "--size", "96x64", "--frames", "4", "--fps", "30", "--batch", "2", "--out", out)
+    assert r.returncode == 0, r.stderr
+    cin = game.compile(src).cinematics[0]
+    times = [k / 30.0 for k in range(4)]
+    rows = cin.uniform_rows(times, 96, 64)
+    an = cin.animator(30.0)
+    an.apply(rows, times)
+    an.close()
+    rd = cin.renderer(96, 64, animate=True)
+    want = rd.render(rows)
+    rd.close()
+    header = b"P6\n96 64\n255\n"
+    frames = []
+    for k in range(4):
+        data = open(f"{out}_{k:05d}.ppm", "rb").read()
+        frames.append(np.frombuffer(data[len(header):], dtype=np.uint8).reshape(64, 96, 3))
+        assert np.array_equal(frames[k], want[k][..., :3])
+    assert not np.array_equal(frames[0], frames[3])
