@@ -44,6 +44,7 @@ def _load():
         "game_program_warning": (c.c_char_p, [vp, sz]),
         "game_front_lex": (c.c_int, [c.c_char_p, sz, c.POINTER(sz), vp, sz]),
         "game_front_tokens": (c.c_char_p, [c.c_char_p, sz]),
+        "game_front_compile_with_imports": (c.c_int, [c.c_char_p, sz, c.c_char_p, vp, sz, c.POINTER(vp)]),
         "game_front_ast_json": (c.c_char_p, [c.c_char_p, sz, c.c_int]),
         "game_builtin_count": (sz, []),
         "game_builtin_describe": (c.c_char_p, [sz]),
@@ -105,6 +106,11 @@ lib, EXPORTED_SYMBOLS = _load()
 
 SEMANTICS = {"glsl": 0, "wgsl": 1}   # GAME_HIP_SEMANTICS_WGSL
 ANIMATE_ARGS = 2                     # GAME_HIP_ANIMATE_ARGS
+LENS_POST = 4                        # GAME_HIP_LENS_POST
+
+
+def _flags(semantics, animate, lens_post):
+    return SEMANTICS[semantics] | (ANIMATE_ARGS if animate else 0) | (LENS_POST if lens_post else 0)
 
 
 def _check(rc):
@@ -196,30 +202,35 @@ class Cinematic:
         """Stateful host-side animation of the user uniforms: arcs, `~` modulation, temporal operators, resonance."""
         return Animator(self, fps)
 
-    def compile_only(self, semantics="glsl", animate=False):
+    def compile_only(self, semantics="glsl", animate=False, lens_post=False):
         """hiprtc-compiles the generated kernels for gfx950 without a device; returns code bytes."""
         n = ctypes.c_size_t()
-        _check(lib.game_hip_compile_only_ex(self._h, SEMANTICS[semantics] | (ANIMATE_ARGS if animate else 0), ctypes.byref(n)))
+        _check(lib.game_hip_compile_only_ex(self._h, _flags(semantics, animate, lens_post), ctypes.byref(n)))
         return n.value
 
     def dump_code(self, path_prefix):
         """Writes the generated kernel source and gfx950 code object next to `path_prefix`."""
         _check(lib.game_hip_dump_code(self._h, path_prefix.encode()))
 
-    def renderer(self, w, h, device=0, semantics="glsl", animate=False):
+    def renderer(self, w, h, device=0, semantics="glsl", animate=False, lens_post=False):
         """semantics: "glsl" = the reference's WebGL2 wording of the builtins (default), "wgsl" = its WebGPU wording.
-        animate: expression-valued stage arguments take their per-frame value instead of the parameter default."""
-        return Renderer(self, w, h, device, semantics, animate)
+        animate: expression-valued stage arguments take their per-frame value instead of the parameter default.
+        lens_post: the `lens { post: ... }` chain runs on the composited colour (the reference ignores it)."""
+        return Renderer(self, w, h, device, semantics, animate, lens_post)
 
 
 class Program:
     """Result of compiling .game source (reference: game_compiler::compile, game-compiler/src/lib.rs:117)."""
 
-    def __init__(self, source):
+    def __init__(self, source, base_dir=None, lib_dirs=()):
         if isinstance(source, str):
             source = source.encode("utf-8")
         h = ctypes.c_void_p()
-        _check(lib.game_front_compile(source, len(source), ctypes.byref(h)))
+        if base_dir is None:
+            _check(lib.game_front_compile(source, len(source), ctypes.byref(h)))
+        else:       # file imports resolved against base_dir, then lib_dirs (reference: resolver::resolve_imports)
+            dirs = (ctypes.c_char_p * max(len(lib_dirs), 1))(*[os.fsencode(d) for d in lib_dirs])
+            _check(lib.game_front_compile_with_imports(source, len(source), os.fsencode(base_dir), dirs, len(lib_dirs), ctypes.byref(h)))
         self._h = h
         n = lib.game_program_cinematic_count(h)
         self.cinematics = [Cinematic(self, lib.game_program_ir(h, i)) for i in range(n)]
@@ -232,8 +243,14 @@ class Program:
             self._h = None
 
 
-def compile(source):
-    return Program(source)
+def compile(source, base_dir=None, lib_dirs=()):
+    """base_dir=None: file imports are left alone, as the reference's compile() does; otherwise they are resolved."""
+    return Program(source, base_dir, lib_dirs)
+
+
+def compile_file(path, lib_dirs=()):
+    with open(path, "rb") as f:
+        return Program(f.read(), os.path.dirname(os.path.abspath(path)), lib_dirs)
 
 
 def lex(source):
@@ -346,11 +363,11 @@ class Animator:
 class Renderer:
     """GPU context for one cinematic at one resolution (reference: GameRendererGL, runtime/helpers.rs:131-241)."""
 
-    def __init__(self, cinematic, w, h, device=0, semantics="glsl", animate=False):
+    def __init__(self, cinematic, w, h, device=0, semantics="glsl", animate=False, lens_post=False):
         self.cinematic = cinematic
         self.w, self.h = w, h
         h_ = ctypes.c_void_p()
-        _check(lib.game_hip_create_ex(cinematic._h, w, h, device, SEMANTICS[semantics] | (ANIMATE_ARGS if animate else 0), ctypes.byref(h_)))
+        _check(lib.game_hip_create_ex(cinematic._h, w, h, device, _flags(semantics, animate, lens_post), ctypes.byref(h_)))
         self._h = h_
 
     def close(self):

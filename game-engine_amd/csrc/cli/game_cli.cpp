@@ -53,7 +53,7 @@ int usage()
             "usage: game check FILE...\n"
             "       game render FILE --hip [--size WxH] [--frames N] [--fps F] [--batch B] [--device D]\n"
             "                   [--cinematic I] [--out PREFIX] [--particles N --steps S]\n"
-            "                   [--png] [--semantics glsl|wgsl] [--no-arcs] [--animate]\n"
+            "                   [--png] [--semantics glsl|wgsl] [--no-arcs] [--animate] [--lens-post] [--imports] [--lib DIR]...\n"
             "       game compare A B [--threshold T]\n"
             "       game ir FILE | game kernel FILE [--size WxH] | game builtins\n");
     return 2;
@@ -61,12 +61,14 @@ int usage()
 
 struct Args {
     std::vector<std::string> files;
-    bool hip = false, png = false, wgsl = false, arcs = true, animate = false;
+    bool hip = false, png = false, wgsl = false, arcs = true, animate = false, lens_post = false;
     int threshold = 2;
     uint32_t w = 1920, h = 1080, frames = 60, batch = 16, cinematic = 0, particles = 0, steps = 1;
     double fps = 60.0;
     int device = 0;
     std::string out;
+    bool imports = false;                 // resolve file imports (resolver.rs) before compiling
+    std::vector<std::string> lib_dirs;
 };
 
 bool parse_args(int argc, char** argv, int first, Args& a)
@@ -81,6 +83,7 @@ bool parse_args(int argc, char** argv, int first, Args& a)
         else if (s == "--png") a.png = true;
         else if (s == "--no-arcs") a.arcs = false;
         else if (s == "--animate") a.animate = true;
+        else if (s == "--lens-post") a.lens_post = true;
         else if (s == "--semantics") {
             const char* v = value("--semantics");
             if (!v) return false;
@@ -94,6 +97,8 @@ bool parse_args(int argc, char** argv, int first, Args& a)
         } else if (s == "--frames") { const char* v = value("--frames"); if (!v) return false; a.frames = (uint32_t)strtoul(v, nullptr, 10); }
         else if (s == "--fps") { const char* v = value("--fps"); if (!v) return false; a.fps = atof(v); }
         else if (s == "--batch") { const char* v = value("--batch"); if (!v) return false; a.batch = (uint32_t)strtoul(v, nullptr, 10); }
+        else if (s == "--imports") a.imports = true;
+        else if (s == "--lib") { const char* v = value("--lib"); if (!v) return false; a.lib_dirs.push_back(v); a.imports = true; }
         else if (s == "--device") { const char* v = value("--device"); if (!v) return false; a.device = atoi(v); }
         else if (s == "--cinematic") { const char* v = value("--cinematic"); if (!v) return false; a.cinematic = (uint32_t)strtoul(v, nullptr, 10); }
         else if (s == "--particles") { const char* v = value("--particles"); if (!v) return false; a.particles = (uint32_t)strtoul(v, nullptr, 10); }
@@ -126,12 +131,22 @@ int cmd_check(const Args& a)
     return had_errors ? 1 : 0;
 }
 
-game_program* load_program(const std::string& path)
+game_program* load_program(const std::string& path, const Args& a)
 {
     std::string src;
     if (!read_file(path, src)) { fprintf(stderr, "Error: read: %s\n", path.c_str()); return nullptr; }
     game_program* prog = nullptr;
-    if (game_front_compile(src.data(), src.size(), &prog) != GAME_OK) {
+    int rc;
+    if (a.imports) {   // imports are looked up next to the file, then in each --lib directory
+        size_t slash = path.find_last_of('/');
+        std::string base = slash == std::string::npos ? "." : path.substr(0, slash ? slash : 1);
+        std::vector<const char*> libs;
+        for (const std::string& d : a.lib_dirs) libs.push_back(d.c_str());
+        rc = game_front_compile_with_imports(src.data(), src.size(), base.c_str(), libs.data(), libs.size(), &prog);
+    } else {
+        rc = game_front_compile(src.data(), src.size(), &prog);
+    }
+    if (rc != GAME_OK) {
         fprintf(stderr, "%s\n", game_last_error_rendered());
         return nullptr;
     }
@@ -304,14 +319,14 @@ int cmd_render(const Args& a)
 {
     if (a.files.size() != 1) return usage();
     if (!a.hip) { fprintf(stderr, "game render: only the --hip back end exists; pass --hip\n"); return 2; }
-    game_program* prog = load_program(a.files[0]);
+    game_program* prog = load_program(a.files[0], a);
     if (!prog) return 1;
     int rc = 1;
     game_hip_ctx* ctx = nullptr;
     do {
         if (a.cinematic >= game_program_cinematic_count(prog)) { fprintf(stderr, "game render: no cinematic %u\n", a.cinematic); break; }
         const game_ir* ir = game_program_ir(prog, a.cinematic);
-        if (game_hip_create_ex(ir, a.w, a.h, a.device, (a.wgsl ? (uint32_t)GAME_HIP_SEMANTICS_WGSL : 0u) | (a.animate ? (uint32_t)GAME_HIP_ANIMATE_ARGS : 0u), &ctx) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
+        if (game_hip_create_ex(ir, a.w, a.h, a.device, (a.wgsl ? (uint32_t)GAME_HIP_SEMANTICS_WGSL : 0u) | (a.animate ? (uint32_t)GAME_HIP_ANIMATE_ARGS : 0u) | (a.lens_post ? (uint32_t)GAME_HIP_LENS_POST : 0u), &ctx) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
         if (a.particles) {
             if (game_hip_particles_seed(ctx, a.particles, 0x9E3779B97F4A7C15ull) != GAME_OK ||
                 game_hip_particles_step(ctx, (float)(1.0 / a.fps), a.steps, 0, a.particles) != GAME_OK || game_hip_sync(ctx) != GAME_OK) {
@@ -387,7 +402,7 @@ int cmd_render(const Args& a)
 int cmd_ir(const Args& a)
 {
     if (a.files.size() != 1) return usage();
-    game_program* prog = load_program(a.files[0]);
+    game_program* prog = load_program(a.files[0], a);
     if (!prog) return 1;
     printf("[");
     for (size_t i = 0; i < game_program_cinematic_count(prog); ++i) printf("%s%s", i ? ",\n" : "", game_ir_json(game_program_ir(prog, i)));
@@ -399,7 +414,7 @@ int cmd_ir(const Args& a)
 int cmd_kernel(const Args& a)
 {
     if (a.files.size() != 1) return usage();
-    game_program* prog = load_program(a.files[0]);
+    game_program* prog = load_program(a.files[0], a);
     if (!prog) return 1;
     int rc = 1;
     // game_hip_dump_code writes the generated source next to the gfx950 code object

@@ -34,13 +34,9 @@ extern "C" {
 const char* game_last_error(void) { return g_last_error.c_str(); }
 const char* game_last_error_rendered(void) { return g_last_rendered.c_str(); }
 
-int game_front_compile(const char* src, size_t len, game_program** out)
+namespace {
+int finish_compile(game_program* p, const CompileError& e, const std::string& source, game_program** out)
 {
-    if (!src || !out) return set_error(GAME_E_ARGUMENT, "game_front_compile: null argument");
-    *out = nullptr;
-    std::string source(src, len);
-    auto* p = new game_program;
-    CompileError e = compile_source(source, p->prog);
     if (!e.ok()) {
         delete p;
         g_last_rendered = e.render_with_source(source);
@@ -56,6 +52,30 @@ int game_front_compile(const char* src, size_t len, game_program** out)
     g_last_rendered.clear();
     *out = p;
     return GAME_OK;
+}
+}  // namespace
+
+int game_front_compile(const char* src, size_t len, game_program** out)
+{
+    if (!src || !out) return set_error(GAME_E_ARGUMENT, "game_front_compile: null argument");
+    *out = nullptr;
+    std::string source(src, len);
+    auto* p = new game_program;
+    CompileError e = compile_source(source, p->prog);
+    return finish_compile(p, e, source, out);
+}
+
+int game_front_compile_with_imports(const char* src, size_t len, const char* base_dir, const char* const* lib_dirs, size_t n_lib_dirs,
+                                    game_program** out)
+{
+    if (!src || !out || !base_dir || (n_lib_dirs && !lib_dirs)) return set_error(GAME_E_ARGUMENT, "game_front_compile_with_imports: null argument");
+    *out = nullptr;
+    std::string source(src, len);
+    std::vector<std::string> libs;
+    for (size_t i = 0; i < n_lib_dirs; ++i) if (lib_dirs[i]) libs.emplace_back(lib_dirs[i]);
+    auto* p = new game_program;
+    CompileError e = compile_source_with_imports(source, base_dir, libs, p->prog);
+    return finish_compile(p, e, source, out);
 }
 
 void game_program_free(game_program* p) { delete p; }

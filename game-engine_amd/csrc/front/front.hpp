@@ -225,6 +225,7 @@ struct IrLayer {
     uint32_t stage_begin = 0, stage_count = 0;
     bool has_memory = false; float decay = 0.0f; std::string decay_text;
     State end_state = State::Position;
+    bool post = false;   // the lens post chain: runs on the composited colour, only when the renderer is asked to
 };
 enum LawOp : uint32_t { LAW_NUM = 0, LAW_DIST, LAW_TIME, LAW_ADD, LAW_SUB, LAW_MUL, LAW_DIV, LAW_POW, LAW_GT, LAW_LT,
                         LAW_NEG, LAW_CALL1, LAW_CALL2, LAW_CALL3, LAW_UNIFORM };
@@ -313,5 +314,10 @@ struct CompiledProgram {
     std::vector<std::string> warnings;   // check() output
 };
 CompileError compile_source(const std::string& src, CompiledProgram& out);
+// resolver.rs:18: drains the file imports of `program`, merging the imported defines into its first cinematic.
+CompileError resolve_imports(Program& program, const std::string& base_dir, const std::vector<std::string>& lib_dirs);
+// compile_source with the file imports resolved between parsing and define expansion.
+CompileError compile_source_with_imports(const std::string& src, const std::string& base_dir,
+                                         const std::vector<std::string>& lib_dirs, CompiledProgram& out);
 
 }  // namespace game

@@ -338,6 +338,58 @@ Ir lower_cinematic(const Cinematic& c)
     std::map<std::string, uint32_t> uslot;
     for (uint32_t i = 0; i < ir.uniforms.size(); ++i) uslot[ir.uniforms[i].name] = i;
 
+    // one stage call -> builtin id + resolved arguments (stages.rs:8-42)
+    auto lower_stage = [&](const Stage& s, const Builtin* b) {
+        IrStage is;
+        is.builtin = b->id;
+        is.name = b->name;
+        is.nargs = b->nparams;
+        for (uint32_t p = 0; p < b->nparams; ++p) {
+            ArgText t = get_arg(s.args, b->params[p].name, p, b->name);
+            IrArg& a = is.args[p];
+            a.text = t.text;
+            if (t.kind == ArgText::Literal) {
+                a.kind = ARG_LIT;
+                a.lit = text_to_f32(t.text);
+            } else if (t.kind == ArgText::Ident) {
+                if (b->id == B_PALETTE) {          // the name is matched as text, never evaluated
+                    a.kind = ARG_LIT; a.lit = 0.0f;
+                } else if (t.text == "time") {
+                    a.kind = ARG_BUILTIN; a.slot = BU_TIME;
+                    ir.flags |= IRF_TIME_IDENT;
+                } else if (uslot.count(t.text)) {
+                    a.kind = ARG_USER; a.slot = uslot[t.text];
+                } else {
+                    a.kind = ARG_LIT; a.lit = 0.0f;
+                    ir.flags |= IRF_BUILTIN_IDENT;
+                }
+            } else {
+                static const struct { const char* n; uint32_t slot; } dotted[] = {
+                    {"audio_bass", BU_AUDIO_BASS}, {"audio_mid", BU_AUDIO_MID}, {"audio_treble", BU_AUDIO_TREBLE},
+                    {"audio_energy", BU_AUDIO_ENERGY}, {"audio_beat", BU_AUDIO_BEAT},
+                    {"mouse_x", BU_MOUSE_X}, {"mouse_y", BU_MOUSE_Y},
+                };
+                bool found = false;
+                for (auto& d : dotted) if (t.text == d.n) { a.kind = ARG_BUILTIN; a.slot = d.slot; found = true; }
+                if (b->id == B_PALETTE) { a.kind = ARG_LIT; a.lit = 0.0f; found = true; }
+                else ir.flags |= IRF_DOTTED_ARG;
+                if (!found) { a.kind = ARG_LIT; a.lit = 0.0f; ir.flags |= IRF_UNKNOWN_DOTTED; }
+            }
+            // an expression the emitters drop: keep it as a frame-level program when it is one
+            // (not for palette names or the fbm octave count, which must stay compile-time values)
+            if (t.dropped && b->id != B_PALETTE && !(b->id == B_FBM && p == 1)) {
+                IrDerived d;
+                if (lower_frame_expr(*t.dropped, uslot, d.prog) && d.prog.size() < 48) {
+                    d.text = expr_source_text(*t.dropped);
+                    a.derived = (int)ir.derived.size();
+                    ir.derived.push_back(std::move(d));
+                }
+            }
+        }
+        if (b->id == B_PALETTE) is.aux = palette_index(is.args[0].text);
+        return is;
+    };
+
     bool any_pipeline = false;
     for (const Layer& l : c.layers) {
         IrLayer il;
@@ -357,53 +409,7 @@ Ir lower_cinematic(const Cinematic& c)
             for (const Stage& s : l.stages) {
                 const Builtin* b = builtin_lookup(s.name);
                 if (!b) continue;   // unreachable after validation
-                IrStage is;
-                is.builtin = b->id;
-                is.name = b->name;
-                is.nargs = b->nparams;
-                for (uint32_t p = 0; p < b->nparams; ++p) {
-                    ArgText t = get_arg(s.args, b->params[p].name, p, b->name);
-                    IrArg& a = is.args[p];
-                    a.text = t.text;
-                    if (t.kind == ArgText::Literal) {
-                        a.kind = ARG_LIT;
-                        a.lit = text_to_f32(t.text);
-                    } else if (t.kind == ArgText::Ident) {
-                        if (b->id == B_PALETTE) {          // the name is matched as text, never evaluated
-                            a.kind = ARG_LIT; a.lit = 0.0f;
-                        } else if (t.text == "time") {
-                            a.kind = ARG_BUILTIN; a.slot = BU_TIME;
-                            ir.flags |= IRF_TIME_IDENT;
-                        } else if (uslot.count(t.text)) {
-                            a.kind = ARG_USER; a.slot = uslot[t.text];
-                        } else {
-                            a.kind = ARG_LIT; a.lit = 0.0f;
-                            ir.flags |= IRF_BUILTIN_IDENT;
-                        }
-                    } else {
-                        static const struct { const char* n; uint32_t slot; } dotted[] = {
-                            {"audio_bass", BU_AUDIO_BASS}, {"audio_mid", BU_AUDIO_MID}, {"audio_treble", BU_AUDIO_TREBLE},
-                            {"audio_energy", BU_AUDIO_ENERGY}, {"audio_beat", BU_AUDIO_BEAT},
-                            {"mouse_x", BU_MOUSE_X}, {"mouse_y", BU_MOUSE_Y},
-                        };
-                        bool found = false;
-                        for (auto& d : dotted) if (t.text == d.n) { a.kind = ARG_BUILTIN; a.slot = d.slot; found = true; }
-                        if (b->id == B_PALETTE) { a.kind = ARG_LIT; a.lit = 0.0f; found = true; }
-                        else ir.flags |= IRF_DOTTED_ARG;
-                        if (!found) { a.kind = ARG_LIT; a.lit = 0.0f; ir.flags |= IRF_UNKNOWN_DOTTED; }
-                    }
-                    // an expression the emitters drop: keep it as a frame-level program when it is one
-                    // (not for palette names or the fbm octave count, which must stay compile-time values)
-                    if (t.dropped && b->id != B_PALETTE && !(b->id == B_FBM && p == 1)) {
-                        IrDerived d;
-                        if (lower_frame_expr(*t.dropped, uslot, d.prog) && d.prog.size() < 48) {
-                            d.text = expr_source_text(*t.dropped);
-                            a.derived = (int)ir.derived.size();
-                            ir.derived.push_back(std::move(d));
-                        }
-                    }
-                }
-                if (b->id == B_PALETTE) is.aux = palette_index(is.args[0].text);
+                IrStage is = lower_stage(s, b);
                 // GLSL scoping facts of the emitted text (glsl.rs:261-531)
                 if (b->input == State::Sdf && !declared.count("sdf_result")) ir.flags |= IRF_COLOR_BEFORE_DECL;
                 if (b->input == State::Color && !declared.count("color_result")) ir.flags |= IRF_COLOR_BEFORE_DECL;
@@ -420,6 +426,29 @@ Ir lower_cinematic(const Cinematic& c)
         ir.layers.push_back(std::move(il));
     }
     if (!any_pipeline) ir.flags |= IRF_NO_OUTPUT;
+
+    // `lens { post: bloom(0.4, 1.5) | grain(0.015) }` (parser.rs:1197-1234): parsed, and ignored by both of the
+    // reference's emitters. The chain is kept as one trailing layer marked `post` that renderers skip unless
+    // asked to apply it to the composited colour; only Color -> Color builtins can run there, others are dropped.
+    // The flags describe the text the reference emits, so this layer must not touch them.
+    {
+        const uint32_t saved_flags = ir.flags;
+        IrLayer pl;
+        pl.name = "lens.post";
+        pl.is_pipeline = true;
+        pl.post = true;
+        pl.end_state = State::Color;
+        pl.stage_begin = (uint32_t)ir.stages.size();
+        for (const Lens& lens : c.lenses)
+            for (const Stage& s : lens.post) {
+                const Builtin* b = builtin_lookup(s.name);
+                if (!b || b->input != State::Color || b->output != State::Color) continue;
+                ir.stages.push_back(lower_stage(s, b));
+            }
+        pl.stage_count = (uint32_t)ir.stages.size() - pl.stage_begin;
+        if (pl.stage_count) ir.layers.push_back(std::move(pl));
+        ir.flags = saved_flags;
+    }
 
     // arc timeline (runtime/arc.rs:62-93): blocks and entries concatenate, the cursor advances by each duration
     double cursor = 0.0;
@@ -653,7 +682,7 @@ std::vector<uint8_t> ir_serialize(const Ir& ir)
         put_u32(b, l.has_memory ? 1 : 0);
         put_f32(b, l.decay);
         put_u32(b, (uint32_t)l.end_state);
-        put_u32(b, 0);
+        put_u32(b, l.post ? 1 : 0);
         put_u32(b, 0);
     }
     for (const IrStage& s : ir.stages) {
@@ -701,7 +730,8 @@ std::string ir_to_json(const Ir& ir)
     for (size_t li = 0; li < ir.layers.size(); ++li) {
         const IrLayer& l = ir.layers[li];
         if (li) j += ",";
-        j += "{\"name\":\"" + json_escape(l.name) + "\",\"pipeline\":" + (l.is_pipeline ? "true" : "false");
+        j += "{\"name\":\"" + json_escape(l.name) + "\",\"pipeline\":" + (l.is_pipeline ? "true" : "false") +
+             ",\"post\":" + (l.post ? "true" : "false");
         j += ",\"memory\":" + (l.has_memory ? "\"" + l.decay_text + "\"" : std::string("null"));
         j += ",\"end_state\":\"" + std::string(state_name(l.end_state)) + "\",\"stages\":[";
         for (uint32_t si = 0; si < l.stage_count; ++si) {
@@ -760,7 +790,8 @@ std::string ir_to_json(const Ir& ir)
 }
 
 // ── whole-source entry point (lib.rs:117-155) ────────────────────────────
-CompileError compile_source(const std::string& src, CompiledProgram& out)
+namespace {
+CompileError compile_impl(const std::string& src, const std::string* base_dir, const std::vector<std::string>* lib_dirs, CompiledProgram& out)
 {
     out = CompiledProgram{};
     std::vector<Token> toks;
@@ -768,6 +799,10 @@ CompileError compile_source(const std::string& src, CompiledProgram& out)
     if (!e.ok()) return e;
     e = parse(std::move(toks), out.ast);
     if (!e.ok()) return e;
+    if (base_dir) {
+        e = resolve_imports(out.ast, *base_dir, *lib_dirs);
+        if (!e.ok()) return e;
+    }
     out.warnings = check_program(out.ast);
     for (Cinematic& c : out.ast.cinematics) (void)expand_defines(c);   // result ignored, like `let _ =` (lib.rs:122)
     for (Cinematic& c : out.ast.cinematics) optimize_cinematic(c);
@@ -779,6 +814,15 @@ CompileError compile_source(const std::string& src, CompiledProgram& out)
         out.jsons.push_back(ir_to_json(out.irs.back()));
     }
     return CompileError{};
+}
+}  // namespace
+
+CompileError compile_source(const std::string& src, CompiledProgram& out) { return compile_impl(src, nullptr, nullptr, out); }
+
+CompileError compile_source_with_imports(const std::string& src, const std::string& base_dir,
+                                         const std::vector<std::string>& lib_dirs, CompiledProgram& out)
+{
+    return compile_impl(src, &base_dir, &lib_dirs, out);
 }
 
 }  // namespace game

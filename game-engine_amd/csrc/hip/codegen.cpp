@@ -187,6 +187,17 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     for (size_t li = 0; li < ir.layers.size(); ++li) {
         const IrLayer& L = ir.layers[li];
         if (!L.is_pipeline || L.end_state != State::Color) continue;
+        if (L.post) {
+            // the lens post chain (ignored by the reference's emitters): Color -> Color stages on the composite
+            if (!shape.lens_post) continue;
+            k += "    {   // lens post\n";
+            k += "        s.px = s.uvx * aspect; s.py = s.uvy; s.sdf = 0.0f; s.r = fr; s.g = fg; s.b = fb; s.a = fa;\n";
+            for (uint32_t si = 0; si < L.stage_count; ++si)
+                k += "        " + stage_call(ir.stages[L.stage_begin + si], shape) + "\n";
+            k += "        fr = s.r; fg = s.g; fb = s.b; fa = s.a;\n";
+            k += "    }\n";
+            continue;
+        }
         k += "    {   // layer " + std::to_string(li) + "\n";
         k += "        s.px = s.uvx * aspect; s.py = s.uvy; s.sdf = 0.0f; s.r = s.g = s.b = s.a = 0.0f;\n";
         for (uint32_t si = 0; si < L.stage_count; ++si)

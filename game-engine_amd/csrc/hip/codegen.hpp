@@ -12,6 +12,7 @@ struct KernelShape {
     bool wgsl = false;              // builtins as worded by the reference's WebGPU emitter (wgsl.rs) where they differ
     bool animate = false;           // expression-valued stage arguments read their per-frame value (Ir::derived)
     uint32_t derived_slot = 0;      // index in the frame row of derived value 0
+    bool lens_post = false;         // run the lens post chain on the composited colour
 };
 
 std::string float_literal(float v);

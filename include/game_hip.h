@@ -51,6 +51,15 @@ const char* game_last_error(void);
  * expand_defines, optimize_cinematic, validate, extract_uniforms. The error text in
  * game_last_error() is the reference's Display text for the same failure. */
 int game_front_compile(const char* src, size_t len, game_program** out);
+/* The same with file imports resolved first (game-compiler/src/resolver.rs:18-147, a library function the
+ * reference's own compile() does not call yet: lib.rs:150 "standard file import - future work"): each
+ * `import "path" ...` is looked up relative to base_dir, then in each library directory, as written and with
+ * ".game" appended; the defines of the imported file (and, transitively, of its imports) are merged into the
+ * first cinematic - all of them for `expose ALL`, the named ones for `expose a, b`, and under the name
+ * "alias.name" for `as alias`. Errors keep the reference's messages ("import not found: 'x'", "circular import
+ * detected: 'x'", ...). URI imports (shadertoy://, midi://, osc://, camera://) are not files and stay inert. */
+int game_front_compile_with_imports(const char* src, size_t len, const char* base_dir, const char* const* lib_dirs,
+                                    size_t n_lib_dirs, game_program** out);
 void game_program_free(game_program* p);
 size_t game_program_cinematic_count(const game_program* p);
 const game_ir* game_program_ir(const game_program* p, size_t index);
@@ -164,7 +173,14 @@ int game_hip_create(const game_ir* ir, uint32_t width, uint32_t height, int devi
  * (game-compiler/src/codegen/wgsl.rs:268-540) words differently from its WebGL2 emitter (star, polygon,
  * simplex, voronoi, concentric_waves, threshold, vignette, chromatic, tonemap, scanlines, glitch, mirror,
  * repeat, curl_noise, displace, spectrum) follow the WebGPU text; flags = 0 is game_hip_create. */
-enum { GAME_HIP_SEMANTICS_WGSL = 1u, GAME_HIP_ANIMATE_ARGS = 2u /* see game_ir_eval_derived */ };
+enum {
+    GAME_HIP_SEMANTICS_WGSL = 1u,
+    GAME_HIP_ANIMATE_ARGS = 2u,   /* see game_ir_eval_derived */
+    /* `lens { post: bloom(0.4, 1.5) | grain(0.015) }` is parsed by the reference (parser.rs:1197-1234) and then ignored
+     * by both of its emitters. With this flag the Color -> Color builtins of the chain run, in order, on the colour
+     * composited from the layers, before the frame is stored (and so before it becomes the next frame's memory). */
+    GAME_HIP_LENS_POST = 4u
+};
 int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int device, uint32_t flags,
                        game_hip_ctx** out);
 void game_hip_destroy(game_hip_ctx* ctx);

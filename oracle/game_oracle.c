@@ -191,6 +191,8 @@ static const float PALETTES[8][12] = {
 /* ── one pixel ─────────────────────────────────────────────────────────────────────────── */
 typedef struct {
     int wgsl;        /* builtins as worded by the WebGPU emitter (wgsl.rs:268-540) where they differ */
+    int lens_post;   /* run the lens post chain (the layer marked pad0 = 1) on the composited colour; the reference's
+                        emitters ignore the chain, so 0 is its behaviour */
     float time;      /* fract(u_time / 120) * 120 */
     float aspect;    /* u_resolution.x / u_resolution.y */
     const float* row;/* this frame's uniform row: 10 built-ins then user uniforms */
@@ -382,9 +384,15 @@ static void shade_pixel(const ir_view* ir, const frame_consts* fc, float uvx, fl
     for (uint32_t li = 0; li < ir->h->n_layers; li++) {
         const ir_layer* L = &ir->layers[li];
         if (!L->is_pipeline) continue;                         /* glsl.rs:229-232 */
+        const int post = L->pad0 == 1u;
+        if (post && !fc->lens_post) continue;
         float px = uvx * fc->aspect, py = uvy;                 /* glsl.rs:240 */
         float sdf = 0.0f;
         float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;
+        if (post) {                                            /* starts from the frame's colour so far */
+            if (multi) { cr = fin_r; cg = fin_g; cb = fin_b; ca = fin_a; }
+            else { cr = frag[0]; cg = frag[1]; cb = frag[2]; ca = frag[3]; }
+        }
         for (uint32_t si = 0; si < L->stage_count; si++) {
             const ir_stage* S = &ir->stages[L->stage_begin + si];
             const float a0 = arg_value(&S->args[0], fc), a1 = arg_value(&S->args[1], fc);
@@ -587,6 +595,11 @@ static void shade_pixel(const ir_view* ir, const frame_consts* fc, float uvx, fl
             (void)a3;
         }
         if (L->end_state != 2) continue;   /* no color_result: the layer contributes nothing */
+        if (post) {
+            if (multi) { fin_r = cr; fin_g = cg; fin_b = cb; fin_a = ca; }
+            else { frag[0] = cr; frag[1] = cg; frag[2] = cb; frag[3] = ca; }
+            continue;
+        }
         if (L->has_memory) {               /* memory.rs:38-45 */
             float pr = (float)(prev & 0xffu) / 255.0f, pg = (float)((prev >> 8) & 0xffu) / 255.0f;
             float pb = (float)((prev >> 16) & 0xffu) / 255.0f, pa = (float)(prev >> 24) / 255.0f;
@@ -652,7 +665,8 @@ int game_oracle_render(const void* blob, size_t blob_len, uint32_t w, uint32_t h
     return game_oracle_render_ex(blob, blob_len, w, h, row0, rows, uniforms, prev_rgba8, out_rgba8, nthreads, 0);
 }
 
-/* semantics: 0 = the WebGL2 wording of every builtin (glsl.rs), 1 = the WebGPU wording where it differs (wgsl.rs). */
+/* semantics, bit 0: 0 = the WebGL2 wording of every builtin (glsl.rs), 1 = the WebGPU wording where it differs
+ * (wgsl.rs). Bit 2 (value 4): also run the lens post chain. */
 int game_oracle_render_ex(const void* blob, size_t blob_len, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows,
                           const float* uniforms, const uint8_t* prev_rgba8, uint8_t* out_rgba8, int nthreads, int semantics)
 {
@@ -668,7 +682,8 @@ int game_oracle_render_ex2(const void* blob, size_t blob_len, uint32_t w, uint32
     ir_view ir;
     if (ir_open(blob, blob_len, &ir) != 0 || !uniforms || !out_rgba8 || w == 0 || h == 0 || row0 + rows > h) return -1;
     frame_consts fc;
-    fc.wgsl = semantics == 1;
+    fc.wgsl = (semantics & 1) != 0;
+    fc.lens_post = (semantics & 4) != 0;
     fc.row = uniforms;
     fc.derived = derived;
     fc.aspect = uniforms[BU_RES_X] / uniforms[BU_RES_Y];               /* glsl.rs:55 */

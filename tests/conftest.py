@@ -59,7 +59,8 @@ class Oracle:
         L.game_oracle_fbm2.argtypes = [c.c_float, c.c_float, c.c_int, c.c_float, c.c_float]
         self.L = L
 
-    def render(self, blob, w, h, row, prev=None, row0=0, rows=None, threads=8, semantics="glsl", derived=None):
+    def render(self, blob, w, h, row, prev=None, row0=0, rows=None, threads=8, semantics="glsl", derived=None,
+               lens_post=False):
         rows = h if rows is None else rows
         row = np.ascontiguousarray(row, dtype=np.float32)
         out = np.zeros((rows, w, 4), dtype=np.uint8)
@@ -70,18 +71,18 @@ class Oracle:
             derived = np.ascontiguousarray(derived, dtype=np.float32)
         rc = self.L.game_oracle_render_ex2(blob, len(blob), w, h, row0, rows, row.ctypes.data,
                                            None if prev is None else prev.ctypes.data, out.ctypes.data, threads,
-                                           {"glsl": 0, "wgsl": 1}[semantics],
+                                           {"glsl": 0, "wgsl": 1}[semantics] | (4 if lens_post else 0),
                                            None if derived is None or derived.size == 0 else derived.ctypes.data)
         assert rc == 0, "oracle rejected the IR blob or arguments"
         return out
 
     def render_sequence(self, blob, w, h, rows_table, uses_memory, row0=0, rows=None, threads=8, semantics="glsl",
-                        derived=None):
+                        derived=None, lens_post=False):
         """derived: None, or one row of expression-argument values per frame."""
         frames, prev = [], None
         for k, r in enumerate(rows_table):
             f = self.render(blob, w, h, r, prev=prev if uses_memory else None, row0=row0, rows=rows, threads=threads,
-                            semantics=semantics, derived=None if derived is None else derived[k])
+                            semantics=semantics, derived=None if derived is None else derived[k], lens_post=lens_post)
             frames.append(f)
             prev = f
         return np.stack(frames)
