@@ -58,10 +58,19 @@ GD void gd_sqrt_rcp_core(float x, float& root, float& inv)
 #endif
     root = g; inv = y;
 }
+// The short sequences and the IEEE expansions agree wherever the short ones are valid, so the choice could
+// be made per wave instead of per lane (one scalar branch on "every active lane is in range"). Measured on
+// MI355X that form is no faster than the exec-mask if/else, so the per-lane form is the default and
+// GD_WAVE_GUARDS selects the other for A/B measurements.
+#ifdef GD_WAVE_GUARDS
+GD bool gd_wave_all(bool ok) { return __builtin_expect(__builtin_amdgcn_ballot_w64(!ok) == 0ull, 1); }
+#else
+GD bool gd_wave_all(bool ok) { return ok; }
+#endif
 GD float gd_sqrt(float x)
 {
     if (__builtin_constant_p(x)) return __builtin_sqrtf(x);
-    if (x >= 0x1p-100f && x < __builtin_inff()) return gd_sqrt_core(x);
+    if (gd_wave_all(x >= 0x1p-100f && x < __builtin_inff())) return gd_sqrt_core(x);
     return __builtin_sqrtf(x);
 }
 // v_fract_f32: x - floor(x) clamped to the largest float below 1; NaN for NaN and infinities.
@@ -80,7 +89,7 @@ GD float gd_rcp(float y)
 {
     if (__builtin_constant_p(y)) return 1.0f / y;
     float a = gd_abs(y);
-    if (a >= 0x1p-126f && a < 0x1p126f) return gd_rcp_core(y);
+    if (gd_wave_all(a >= 0x1p-126f && a < 0x1p126f)) return gd_rcp_core(y);
     return 1.0f / y;
 }
 GD float gd_mod(float x, float y) { return x - y * gd_floor(x * gd_rcp(y)); }
@@ -842,16 +851,15 @@ GD void gw_spectrum(GdPix& s, float bass, float mid, float treble)              
     s.a = 1.0f;
 }
 
-// b / 255 for b in 0..255, correctly rounded, without the division sequence: q = b * RN(1/255) is
-// within one ulp, the residual b - 255 q is exact in one fma, and the corrected q is the correctly
-// rounded quotient for every one of the 256 inputs (checked exhaustively by the tests).
+// b / 255 for b in 0..255, correctly rounded, without the division sequence: 1/255 split into a float
+// and the float nearest to what is left (hi + lo = 1/255 to 2^-57), b * lo rounded once and folded into
+// b * hi by one fma. The result is the correctly rounded quotient for every one of the 256 inputs
+// (checked exhaustively by the tests).
 GD float gd_unorm8_to_float(gd_u32 b)
 {
-    const float r = 0x1.010102p-8f;
+    const float hi = 0x1.010102p-8f, lo = -0x1.fdfdfep-33f;
     float u = (float)b;
-    float q = u * r;
-    float e = __builtin_fmaf(-q, 255.0f, u);
-    return __builtin_fmaf(e, r, q);
+    return __builtin_fmaf(u, hi, u * lo);
 }
 // Memory feedback (game-compiler/src/codegen/memory.rs:38-45): mix with the previous frame's
 // RGBA8 texel at the same pixel.

@@ -30,6 +30,7 @@ struct game_hip_ctx {
     std::string source;
     KernelShape shape;
     uint32_t row_floats = 0, ustride = 0;
+    unsigned lds_bytes = 0;   // dynamic LDS requested per workgroup: unused by the kernel, caps resident workgroups per CU
     // frame ring
     uint32_t ring = 0, next_slot = 0;
     int last_slot = -1;
@@ -161,7 +162,7 @@ KernelShape shape_for(const Ir& ir, uint32_t width, uint32_t flags = 0)
     s.pixels_per_lane = (!heavy && width % 4u == 0u) ? 4u : 1u;
     if (const char* e = getenv("GAME_HIP_PPL")) {   // tuning hook
         int v = atoi(e);
-        if (v == 1 || (v == 4 && width % 4u == 0u)) s.pixels_per_lane = (uint32_t)v;
+        if (v == 1 || ((v == 4 || v == 8 || v == 16) && width % 4u == 0u)) s.pixels_per_lane = (uint32_t)v;
     }
     uint32_t row = BU_COUNT + (uint32_t)ir.uniforms.size();
     s.time_slot = row;
@@ -234,9 +235,7 @@ int launch_frames(game_hip_ctx* c, uint32_t frame0, uint32_t count, uint32_t slo
     void* args[] = {&P};
     uint32_t gx = (c->w + 256u * c->shape.pixels_per_lane - 1u) / (256u * c->shape.pixels_per_lane);
     uint32_t gy = rows;   // one row per workgroup row; rows <= height <= 65535 is checked at creation
-    // Tuning hook: dynamic LDS request per workgroup, to cap resident workgroups per CU.
-    static const unsigned lds_bytes = getenv("GAME_HIP_LDS_BYTES") ? (unsigned)atoi(getenv("GAME_HIP_LDS_BYTES")) : 0u;
-    HIP_TRY(hipModuleLaunchKernel(c->fn, gx, gy, count, 256, 1, 1, lds_bytes, c->stream, args, nullptr));
+    HIP_TRY(hipModuleLaunchKernel(c->fn, gx, gy, count, 256, 1, 1, c->lds_bytes, c->stream, args, nullptr));
     return GAME_OK;
 }
 
@@ -374,6 +373,7 @@ int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int d
     c->device = device;
     c->w = width; c->h = height;
     c->shape = shape_for(c->ir, c->w, flags);
+    if (const char* e = getenv("GAME_HIP_LDS_BYTES")) c->lds_bytes = (unsigned)atoi(e);   // tuning hook, read per context
     c->row_floats = BU_COUNT + (uint32_t)c->ir.uniforms.size();
     c->ustride = c->row_floats + 2 + (c->shape.animate ? (uint32_t)c->ir.derived.size() : 0u);
     c->source = generate_frame_kernel(c->ir, c->shape);
