@@ -241,7 +241,7 @@ GD float gd_noise2(float px, float py)
 // thousand distinct points per octave while every pixel needs four of them per noise2 call, so the
 // runtime tabulates hash2 over the integer points of [-512, 512]^2 once per device. Entry (iy + 512,
 // ix + 512) holds the pair {hash2(ix, iy), hash2(ix, iy + 1)} (GD_LUT_STRIDE pairs per row), so the four
-// corners of a cell are one 16-byte load; noise2 then costs one range test, a five-instruction index
+// corners of a cell are one 16-byte load; noise2 then costs one range test, a three-instruction index
 // and that load instead of four hash evaluations. Points outside the table, and a null table,
 // take the arithmetic path; both paths return the same bits because the table is filled by gd_hash2.
 #define GD_LUT_STRIDE 2048u
@@ -250,6 +250,16 @@ GD float gd_noise2(float px, float py)
 // One noise2 evaluation split in two, so that callers needing several values (the fbm octaves, the two
 // components of a warp) can test all their lattice cells first, issue all table loads back to back, and
 // only then combine: the loads of one call overlap instead of each waiting out its own latency.
+// Byte offset of table entry (iy + 512 + d, ix + 512 + d) for integral ix, iy inside the table and d = 0 or -1.
+// The entry number k = (iy + 512 + d) * 2048 + (ix + 512 + d) is computed in floating point: iy * 2048 + ix is
+// exact (below 2^21), adding 1.5 * 2^23 + (512 + d) * 2049 is exact too and leaves 0x4B400000 + k in the bits;
+// shifting left by 3 drops the exponent's top bits, and subtracting what is left of them gives 8 k.
+// Three instructions: fma, add, shift-and-add.
+GD gd_u32 gd_lut_offset(float ix, float iy, float d)
+{
+    const float t = __builtin_fmaf(iy, 2048.0f, ix);
+    return (gd_bits(t + (12582912.0f + (512.0f + d) * 2049.0f)) << 3) - 0x5A000000u;
+}
 struct GdCell {
     float ix, iy;    // lattice cell
     float ux, uy;    // Hermite weights of the fractional part
@@ -264,9 +274,7 @@ GD GdCell gd_cell(float px, float py)
     c.ux = fx * fx * __builtin_fmaf(-2.0f, fx, 3.0f);
     c.uy = fy * fy * __builtin_fmaf(-2.0f, fy, 3.0f);
     c.ok = gd_abs(c.ix) <= 511.0f && gd_abs(c.iy) <= 511.0f;
-    // ix + (1.5 * 2^23 + 512) is exact and its low 11 significand bits are ix + 512
-    gd_u32 u = gd_bits(c.ix + 12583424.0f) & 0x7ffu, v = gd_bits(c.iy + 12583424.0f) & 0x7ffu;
-    c.off = (v << 14) | (u << 3);
+    c.off = gd_lut_offset(c.ix, c.iy, 0.0f);
     return c;
 }
 struct GdCorners { float a, b, c, d; };
@@ -431,9 +439,7 @@ GD float gd_voronoi2d_lut(float px, float py, float scale, const float* __restri
     float ipx = gd_floor(psx), ipy = gd_floor(psy);
     if (!(vlut != nullptr && gd_abs(ipx) <= 510.0f && gd_abs(ipy) <= 510.0f)) return gd_voronoi2d(px, py, scale);
     float fpx = gd_fract(psx), fpy = gd_fract(psy);
-    // ipx + (1.5 * 2^23 + 511) is exact; its low 11 significand bits are (ipx - 1) + 512
-    gd_u32 u = gd_bits(ipx + 12583423.0f) & 0x7ffu, v = gd_bits(ipy + 12583423.0f) & 0x7ffu;
-    const char* base = (const char*)vlut + ((v << 14) | (u << 3));
+    const char* base = (const char*)vlut + gd_lut_offset(ipx, ipy, -1.0f);   // entry (ipy - 1, ipx - 1)
     float d = 1.0f;
 #pragma unroll
     for (int y = -1; y <= 1; y++) {
@@ -700,8 +706,7 @@ GD void gw_hash2v(float x, float y, const float* __restrict__ vlut, float& hx, f
 {
     float fx, fy;
     if (vlut != nullptr && gd_abs(x) <= 512.0f && gd_abs(y) <= 512.0f) {
-        gd_u32 u = gd_bits(x + 12583424.0f) & 0x7ffu, v = gd_bits(y + 12583424.0f) & 0x7ffu;
-        gd_f32x2 e = *(const gd_f32x2*)((const char*)vlut + ((v << 14) | (u << 3)));
+        gd_f32x2 e = *(const gd_f32x2*)((const char*)vlut + gd_lut_offset(x, y, 0.0f));
         fx = e[0]; fy = e[1];
     } else {
         fx = gd_fract(gd_sin(x * 127.1f + y * 311.7f) * 43758.5453f);
@@ -741,8 +746,7 @@ GD float gw_voronoi2(float px, float py, float scale, const float* __restrict__ 
     float h[3][3];
     if (table) {
         // rows ipy - 1 and ipy of the pair table hold {h(y-1), h(y)} and {h(y), h(y+1)} for columns ipx - 1 .. ipx + 1
-        gd_u32 u = gd_bits(ipx + 12583423.0f) & 0x7ffu, v = gd_bits(ipy + 12583423.0f) & 0x7ffu;
-        const char* base = (const char*)lut + ((v << 14) | (u << 3));
+        const char* base = (const char*)lut + gd_lut_offset(ipx, ipy, -1.0f);
         gd_f32x4_a8 lo01 = *(const gd_f32x4_a8*)base;
         gd_f32x2 lo2 = *(const gd_f32x2*)(base + 16);
         gd_f32x4_a8 hi01 = *(const gd_f32x4_a8*)(base + GD_LUT_STRIDE * 8u);
