@@ -329,14 +329,16 @@ GD float gd_fbm2(float px, float py, int octaves, float persistence, float lacun
 {
     if (lut != nullptr && __builtin_constant_p(octaves) && octaves >= 1 && octaves <= 8) {
         // literal octave count: all cells first, then (when every cell is inside the table) all loads, then the sum
+        // One range test for all octaves: octave i samples at (rotation^i p) * frequency_i, whose Euclidean norm
+        // is |p| * frequency_i up to a few ulps, so |p|^2 * max(frequency)^2 <= 509^2 keeps every lattice cell of
+        // every octave within [-510, 510] (two cells of margin inside the table; NaN fails the test).
         GdCell cell[8];
         float amp[8];
-        float amplitude = 1.0f, frequency = 1.0f, max_val = 0.0f, qx = px, qy = py;
-        bool ok = true;
+        float amplitude = 1.0f, frequency = 1.0f, max_val = 0.0f, qx = px, qy = py, fmax = 1.0f;
 #pragma unroll
         for (int i = 0; i < octaves; i++) {
             cell[i] = gd_cell(qx * frequency, qy * frequency);
-            ok = ok && cell[i].ok;
+            fmax = !(gd_abs(frequency) <= fmax) ? gd_abs(frequency) : fmax;   // a NaN frequency makes fmax NaN: the test fails
             amp[i] = amplitude;
             max_val = max_val + amplitude;
             amplitude = amplitude * persistence;
@@ -345,6 +347,7 @@ GD float gd_fbm2(float px, float py, int octaves, float persistence, float lacun
             float ny = __builtin_fmaf(qx, 0.6f, qy * 0.8f);
             qx = nx; qy = ny;
         }
+        const bool ok = __builtin_fmaf(px, px, py * py) * (fmax * fmax) <= 259081.0f;
         GdCorners k[8];
         if (ok) {
 #pragma unroll

@@ -404,3 +404,31 @@ def test_gravity_index_sharding(game, oracle):
         pa = np.concatenate([qa[:600], qb[600:]]); va = np.concatenate([wa[:600], wb[600:]])   # the all-gather
     a.close(); b.close()
     assert np.array_equal(pa, want[:, :2]) and np.array_equal(va, want[:, 2:])
+
+
+@pytest.mark.gpu
+def test_fbm_table_range_test_edges(game, oracle):
+    """fbm decides table vs arithmetic with one norm test for all octaves: frames that straddle the table's edge,
+    and frequencies that are negative, shrinking, zero, infinite or NaN, must still equal the oracle (and must
+    never index the table with a cell outside it)."""
+    src = 'cinematic "e" { layer a { fn: translate(tx, 0.0) | fbm(sc, 5.0, pe, la) | glow(1.5) | tint(0.7, 0.9, 1.0) } }'
+    cin = game.compile(src).cinematics[0]
+    w, h = 192, 108
+    nan, inf = float("nan"), float("inf")
+    cases = [  # sc, pe, la, tx
+        (3.0, 0.5, 2.0, 0.0), (30.0, 0.5, 2.0, 0.0), (17.9, 0.5, 2.0, 0.0), (18.1, 0.5, 2.0, 0.0), (200.0, 0.5, 2.0, 0.0),
+        (3.0, 0.5, -2.0, 0.0), (300.0, 0.5, 0.5, 0.0), (500.0, 0.5, 0.25, 1.0), (3.0, 0.5, 0.0, 0.0), (3.0, 0.5, inf, 0.0),
+        (3.0, 0.5, nan, 0.0), (3.0, nan, 2.0, 0.0), (nan, 0.5, 2.0, 0.0), (inf, 0.5, 2.0, 0.0), (3.0, 0.5, 2.0, 1e30),
+        (511.0, 0.5, 1.0, 0.0), (287.0, 0.5, 1.0, 0.0), (3.0, 0.5, 1e-30, 0.0), (-31.0, 0.5, 2.0, 0.3),
+    ]
+    rows = cin.uniform_rows([0.0] * len(cases), w, h)
+    names = [u["name"] for u in cin.ir["uniforms"]]
+    for k, (sc, pe, la, tx) in enumerate(cases):
+        for name, v in (("sc", sc), ("pe", pe), ("la", la), ("tx", tx)):
+            rows[k, 10 + names.index(name)] = v
+    r = cin.renderer(w, h)
+    got = r.render(rows)
+    r.close()
+    want = oracle.render_sequence(cin.blob, w, h, rows, False)
+    for k in range(len(cases)):
+        assert np.array_equal(got[k], want[k]), f"case {cases[k]}"
