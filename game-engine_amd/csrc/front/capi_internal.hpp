@@ -20,7 +20,7 @@ namespace game {
 extern thread_local std::string g_last_error;
 int set_error(int code, const std::string& msg);
 // Tables of the current HIP device (see game_device.h): kind 0 = lattice hash pairs, 1 = voronoi feature
-// points. Built on first use and kept for the life of the process. Defined with the ahead-of-time
+// points, 2 = simplex corners. Built on first use and kept for the life of the process. Defined with the ahead-of-time
 // kernels; returns a GAME_E_* code.
 int lut_for_current_device(int kind, const float** table);
 int error_code_of(const CompileError& e);

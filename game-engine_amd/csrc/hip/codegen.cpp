@@ -145,6 +145,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
          "    float inv_w, inv_h;\n"
          "    const float* lut;\n"
          "    const float* vlut;\n"
+         "    const float* slut;\n"
          "};\n\n";
     k += "extern \"C\" __global__ __launch_bounds__(256) void game_frame(GameFrameParams P)\n{\n";
     // A lane owns pixels_per_lane consecutive pixels of one row, a wave 64 * pixels_per_lane of them,
@@ -166,7 +167,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     k += "    const gd_u32 slot = slot_raw >= P.ring ? slot_raw - P.ring : slot_raw;\n";
     k += "    gd_u32* __restrict__ dst = P.out + (unsigned long long)slot * P.frame_pixels + (unsigned long long)ty * P.w;\n";
     k += "    GdPix s;\n";
-    k += "    s.lut = P.lut; s.vlut = P.vlut;\n";
+    k += "    s.lut = P.lut; s.vlut = P.vlut; s.slut = P.slut;\n";
     k += "    s.time = U[" + std::to_string(shape.time_slot) + "];\n";
     k += "    const float aspect = U[" + std::to_string(shape.aspect_slot) + "];\n";
     k += "    s.bass = U[1]; s.mid = U[2]; s.treble = U[3];\n";

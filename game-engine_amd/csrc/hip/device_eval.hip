@@ -13,7 +13,7 @@ using namespace game;
 namespace {
 
 enum EvalOp { EV_FRACT = 0, EV_SIN, EV_COS, EV_ATAN2, EV_HASH2, EV_NOISE2, EV_SIMPLEX, EV_VORONOI, EV_EXP2, EV_LOG2, EV_POW,
-              EV_MAX, EV_MIN, EV_FBM6, EV_SQRT, EV_DIV, EV_SMOOTHSTEP_GLOW, EV_MOD, EV_UNORM8, EV_NOISE2_LUT, EV_FBM6_LUT, EV_VORONOI_LUT, EV_COUNT };
+              EV_MAX, EV_MIN, EV_FBM6, EV_SQRT, EV_DIV, EV_SMOOTHSTEP_GLOW, EV_MOD, EV_UNORM8, EV_NOISE2_LUT, EV_FBM6_LUT, EV_VORONOI_LUT, EV_SIMPLEX_LUT, EV_COUNT };
 
 // Fills the lattice-hash table: entry (row iy + 512, column ix + 512) = {hash2(ix, iy), hash2(ix, iy + 1)}.
 __global__ void hash_lut_fill(float* __restrict__ table)
@@ -35,6 +35,16 @@ __global__ void voronoi_lut_fill(float* __restrict__ table)
     float* e = table + ((size_t)v * GD_LUT_STRIDE + u) * 2u;
     e[0] = gd_fract(gd_sin(cx * 127.1f + cy * 311.7f) * 43758.5453f);
     e[1] = gd_fract(gd_sin(cx * 269.5f + cy * 183.3f) * 43758.5453f);
+}
+
+// Fills the simplex corner table: entry (row Y, column X), X, Y in [0, 289] = gd_simplex_corner(permute(permute(Y) + X)).
+__global__ void simplex_lut_fill(float* __restrict__ table)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+    if (u >= GD_SIMPLEX_DIM) return;
+    const GdSimplexCorner c = gd_simplex_corner(gd_permute(gd_permute((float)v) + (float)u));
+    float* e = table + ((size_t)v * GD_SIMPLEX_DIM + u) * 4u;
+    e[0] = c.a0; e[1] = c.h; e[2] = c.nrm; e[3] = 0.0f;
 }
 
 __global__ void eval_kernel(int op, uint32_t n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
@@ -66,6 +76,7 @@ __global__ void eval_kernel(int op, uint32_t n, const float* __restrict__ a, con
     case EV_NOISE2_LUT: r = gd_noise2_lut(x, y, lut); break;
     case EV_FBM6_LUT: r = gd_fbm2(x, y, 6, 0.5f, 2.0f, lut); break;
     case EV_VORONOI_LUT: r = gd_voronoi2d_lut(x, y, 5.0f, lut); break;
+    case EV_SIMPLEX_LUT: r = gd_simplex2d(x, y, lut); break;
     default: break;
     }
     out[i] = r;
@@ -134,19 +145,22 @@ namespace game {
 int lut_for_current_device(int kind, const float** table)
 {
     static std::mutex mu;
-    static std::map<int, float*> tables;   // key = device * 2 + kind
+    static std::map<int, float*> tables;   // key = device * 4 + kind
+    if (kind < 0 || kind > 2) return set_error(GAME_E_ARGUMENT, "lut_for_current_device: unknown table");
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    dev = dev * 2 + (kind ? 1 : 0);
+    dev = dev * 4 + kind;
     std::lock_guard<std::mutex> lock(mu);
     auto it = tables.find(dev);
     if (it == tables.end()) {
         float* t = nullptr;
-        const size_t bytes = (size_t)GD_LUT_ROWS * GD_LUT_STRIDE * 2u * sizeof(float);
+        const size_t bytes = kind == 2 ? (size_t)GD_SIMPLEX_DIM * GD_SIMPLEX_DIM * 4u * sizeof(float)
+                                       : (size_t)GD_LUT_ROWS * GD_LUT_STRIDE * 2u * sizeof(float);
         HIP_TRY(hipMalloc((void**)&t, bytes));
         hipError_t e = hipMemset(t, 0, bytes);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(kind ? voronoi_lut_fill : hash_lut_fill, dim3((GD_LUT_ROWS + 255u) / 256u, GD_LUT_ROWS), dim3(256), 0, 0, t);
+            if (kind == 2) hipLaunchKernelGGL(simplex_lut_fill, dim3((GD_SIMPLEX_DIM + 255u) / 256u, GD_SIMPLEX_DIM), dim3(256), 0, 0, t);
+            else hipLaunchKernelGGL(kind ? voronoi_lut_fill : hash_lut_fill, dim3((GD_LUT_ROWS + 255u) / 256u, GD_LUT_ROWS), dim3(256), 0, 0, t);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -171,8 +185,8 @@ int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out
     HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
     if (b) { HIP_TRY(db.alloc(bytes)); HIP_TRY(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice)); }
     const float* lut = nullptr;
-    if (op == EV_NOISE2_LUT || op == EV_FBM6_LUT || op == EV_VORONOI_LUT) {
-        int rc = lut_for_current_device(op == EV_VORONOI_LUT ? 1 : 0, &lut);
+    if (op == EV_NOISE2_LUT || op == EV_FBM6_LUT || op == EV_VORONOI_LUT || op == EV_SIMPLEX_LUT) {
+        int rc = lut_for_current_device(op == EV_VORONOI_LUT ? 1 : op == EV_SIMPLEX_LUT ? 2 : 0, &lut);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(eval_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op, n, (const float*)da.p, (const float*)db.p, (float*)dout.p, lut);

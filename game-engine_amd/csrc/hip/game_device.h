@@ -378,9 +378,27 @@ GD float gd_fbm2(float px, float py, int octaves, float persistence, float lacun
 
 GD float gd_permute(float x) { return gd_mod((x * 34.0f + 1.0f) * x, 289.0f); }   // glsl.rs:173-175
 
-GD float gd_simplex2d(float vx, float vy)   // glsl.rs:176-198
+// What a simplex corner contributes beyond its distance falloff depends only on the permuted lattice value p:
+// the gradient (a0, h) and its normalisation factor (glsl.rs:187-194).
+struct GdSimplexCorner { float a0, h, nrm; };
+GD GdSimplexCorner gd_simplex_corner(float p)
 {
-    const float Cx = 0.211324865405187f, Cy = 0.366025403784439f, Cz = -0.577350269189626f, Cw = 0.024390243902439f;
+    const float Cw = 0.024390243902439f;
+    GdSimplexCorner c;
+    float xv = 2.0f * gd_fract(p * Cw) - 1.0f;
+    c.h = gd_abs(xv) - 0.5f;
+    c.a0 = xv - gd_floor(xv + 0.5f);
+    c.nrm = 1.79284291400159f - 0.85373472095314f * (c.a0 * c.a0 + c.h * c.h);
+    return c;
+}
+// p = permute(permute(Y) + X) for the lattice point (X, Y) after the mod-289 wrap: a pure function of two
+// integers in [0, 289], so the runtime tabulates gd_simplex_corner of it once per device: 290 rows of 290
+// entries {a0, h, nrm, 0} (1.35 MB), filled by this same code. A pixel then reads its three corners as three
+// 16-byte loads instead of evaluating six permutes and three gradient set-ups.
+#define GD_SIMPLEX_DIM 290u
+GD float gd_simplex2d(float vx, float vy, const float* __restrict__ slut = nullptr)   // glsl.rs:176-198
+{
+    const float Cx = 0.211324865405187f, Cy = 0.366025403784439f, Cz = -0.577350269189626f;
     float dv = vx * Cy + vy * Cy;
     float ix = gd_floor(vx + dv), iy = gd_floor(vy + dv);
     float di = ix * Cx + iy * Cx;
@@ -390,25 +408,35 @@ GD float gd_simplex2d(float vx, float vy)   // glsl.rs:176-198
     float x12x = x0x + Cx, x12y = x0y + Cx, x12z = x0x + Cz, x12w = x0y + Cz;
     x12x = x12x - i1x; x12y = x12y - i1y;
     ix = gd_mod(ix, 289.0f); iy = gd_mod(iy, 289.0f);
-    float p0 = gd_permute(gd_permute(iy + 0.0f) + ix + 0.0f);
-    float p1 = gd_permute(gd_permute(iy + i1y) + ix + i1x);
-    float p2 = gd_permute(gd_permute(iy + 1.0f) + ix + 1.0f);
+    GdSimplexCorner c0, c1, c2;
+    // the wrap leaves integers in [0, 288] for every finite coordinate below 2^24; anything else (NaN included)
+    // fails the test and takes the arithmetic path
+    if (slut != nullptr && ix >= 0.0f && ix <= 288.0f && iy >= 0.0f && iy <= 288.0f) {
+        // entry number k = iy * 290 + ix as exact float arithmetic; (bits(k + 1.5 * 2^23) << 4) - 0xB4000000 = 16 k
+        const gd_u32 off = (gd_bits(__builtin_fmaf(iy, 290.0f, ix) + 12582912.0f) << 4) - 0xB4000000u;
+        const char* base = (const char*)slut + off;
+        const gd_f32x4_a8 e0 = *(const gd_f32x4_a8*)base;
+        const gd_f32x4_a8 e1 = *(const gd_f32x4_a8*)(base + (gt ? 16u : GD_SIMPLEX_DIM * 16u));
+        const gd_f32x4_a8 e2 = *(const gd_f32x4_a8*)(base + (GD_SIMPLEX_DIM + 1u) * 16u);
+        c0.a0 = e0[0]; c0.h = e0[1]; c0.nrm = e0[2];
+        c1.a0 = e1[0]; c1.h = e1[1]; c1.nrm = e1[2];
+        c2.a0 = e2[0]; c2.h = e2[1]; c2.nrm = e2[2];
+    } else {
+        c0 = gd_simplex_corner(gd_permute(gd_permute(iy + 0.0f) + ix + 0.0f));
+        c1 = gd_simplex_corner(gd_permute(gd_permute(iy + i1y) + ix + i1x));
+        c2 = gd_simplex_corner(gd_permute(gd_permute(iy + 1.0f) + ix + 1.0f));
+    }
     float m0 = gd_max(0.5f - (x0x * x0x + x0y * x0y), 0.0f);
     float m1 = gd_max(0.5f - (x12x * x12x + x12y * x12y), 0.0f);
     float m2 = gd_max(0.5f - (x12z * x12z + x12w * x12w), 0.0f);
     m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
     m0 = m0 * m0; m1 = m1 * m1; m2 = m2 * m2;
-    float xv0 = 2.0f * gd_fract(p0 * Cw) - 1.0f;
-    float xv1 = 2.0f * gd_fract(p1 * Cw) - 1.0f;
-    float xv2 = 2.0f * gd_fract(p2 * Cw) - 1.0f;
-    float h0 = gd_abs(xv0) - 0.5f, h1 = gd_abs(xv1) - 0.5f, h2 = gd_abs(xv2) - 0.5f;
-    float a00 = xv0 - gd_floor(xv0 + 0.5f), a01 = xv1 - gd_floor(xv1 + 0.5f), a02 = xv2 - gd_floor(xv2 + 0.5f);
-    m0 = m0 * (1.79284291400159f - 0.85373472095314f * (a00 * a00 + h0 * h0));
-    m1 = m1 * (1.79284291400159f - 0.85373472095314f * (a01 * a01 + h1 * h1));
-    m2 = m2 * (1.79284291400159f - 0.85373472095314f * (a02 * a02 + h2 * h2));
-    float g0 = a00 * x0x + h0 * x0y;
-    float g1 = a01 * x12x + h1 * x12y;
-    float g2 = a02 * x12z + h2 * x12w;
+    m0 = m0 * c0.nrm;
+    m1 = m1 * c1.nrm;
+    m2 = m2 * c2.nrm;
+    float g0 = c0.a0 * x0x + c0.h * x0y;
+    float g1 = c1.a0 * x12x + c1.h * x12y;
+    float g2 = c2.a0 * x12z + c2.h * x12w;
     return 130.0f * (m0 * g0 + m1 * g1 + m2 * g2);
 }
 
@@ -479,6 +507,7 @@ struct GdPix {
     float bass, mid, treble;
     const float* lut;      // lattice-hash table (uniform; may be null)
     const float* vlut;     // voronoi feature-point table (uniform; may be null)
+    const float* slut;     // simplex corner table (uniform; may be null)
 };
 
 // SDF generators: Position -> Sdf
@@ -514,7 +543,7 @@ GD void gb_polygon(GdPix& s, float sides, float radius)                         
     float sector = gd_cos(gd_floor(0.5f + a / an) * an - a) * r;
     s.sdf = sector - radius;
 }
-GD void gb_simplex(GdPix& s, float scale) { s.sdf = gd_simplex2d(s.px * scale, s.py * scale); }         // :305-308
+GD void gb_simplex(GdPix& s, float scale) { s.sdf = gd_simplex2d(s.px * scale, s.py * scale, s.slut); }         // :305-308
 GD void gb_voronoi(GdPix& s, float scale) { s.sdf = gd_voronoi2d_lut(s.px, s.py, scale, s.vlut); }                  // :309-312
 GD void gb_concentric_waves(GdPix& s, float amplitude, float width, float frequency)                    // :313-319
 {

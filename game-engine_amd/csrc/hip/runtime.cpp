@@ -39,6 +39,7 @@ struct game_hip_ctx {
     size_t utab_cap = 0;
     const float* lut = nullptr;   // lattice-hash table of this device (shared, not owned)
     const float* vlut = nullptr;  // voronoi feature-point table of this device (shared, not owned)
+    const float* slut = nullptr;  // simplex corner table of this device (shared, not owned)
     std::vector<float> utab_host;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.0f;
@@ -68,6 +69,7 @@ struct FrameParams {
     float inv_w, inv_h;
     const float* lut;
     const float* vlut;
+    const float* slut;
 };
 struct GravityParams {
     const float* xin; const float* yin;
@@ -232,6 +234,7 @@ int launch_frames(game_hip_ctx* c, uint32_t frame0, uint32_t count, uint32_t slo
     P.inv_h = 1.0f / (float)c->h;
     P.lut = c->lut;
     P.vlut = c->vlut;
+    P.slut = c->slut;
     void* args[] = {&P};
     uint32_t gx = (c->w + 256u * c->shape.pixels_per_lane - 1u) / (256u * c->shape.pixels_per_lane);
     uint32_t gy = rows;   // one row per workgroup row; rows <= height <= 65535 is checked at creation
@@ -401,6 +404,10 @@ int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int d
     }
     if (uses_builtin(c->ir, wgsl ? B_SIMPLEX : B_VORONOI) && !getenv("GAME_HIP_NO_LUT")) {
         rc = lut_for_current_device(1, &c->vlut);
+        if (rc) { game_hip_destroy(c); return rc; }
+    }
+    if (!wgsl && uses_builtin(c->ir, B_SIMPLEX) && !getenv("GAME_HIP_NO_LUT")) {
+        rc = lut_for_current_device(2, &c->slut);
         if (rc) { game_hip_destroy(c); return rc; }
     }
     if (c->ir.gravity.present) {

@@ -241,7 +241,7 @@ int game_hip_particles_time(game_hip_ctx* ctx, float* sim_time);
  * 4 hash2(a,b), 5 noise2(a,b), 6 simplex2d(a,b), 7 voronoi2d(a,b,5), 8 exp2, 9 log2, 10 pow(a,b),
  * 11 max(a,b), 12 min(a,b), 13 fbm2(a,b,6,.5,2), 14 sqrt, 15 a/b, 16 smoothstep(.005,-.005,a),
  * 17 mod(a,b), 18 unorm8 -> float of (uint)a, 19 / 20 noise2 / fbm2 through the lattice-hash table,
- * 21 voronoi2d(a,b,5) through the feature-point table.
+ * 21 voronoi2d(a,b,5) through the feature-point table, 22 simplex2d(a,b) through the corner table.
  * b may be NULL for one-argument ops. */
 int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out);
 /* Exhaustive check, over all 2^32 float bit patterns, that the hardware instruction equals its

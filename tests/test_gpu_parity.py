@@ -112,6 +112,23 @@ def test_lattice_hash_table_path_equals_arithmetic_path(game):
         assert same.all(), (lut_op, xy[~same][:5], got[~same][:5], want[~same][:5])
 
 
+@pytest.mark.gpu
+def test_simplex_corner_table_path_equals_arithmetic_path(game):
+    """simplex2d through the per-device corner table against the arithmetic path: ordinary coordinates, the
+    mod-289 wrap (cells 288 | 0 and negatives), magnitudes where the wrap stops yielding integers, non-finite."""
+    rng = np.random.default_rng(23)
+    n = 200000
+    parts = [(rng.random((n, 2), dtype=np.float32) * 2 - 1) * np.float32(s) for s in (3.0, 300.0, 1.0e5, 3.0e7, 1.0e12)]
+    edge = np.array([[288.2, 0.3], [288.9, 288.9], [289.0, 289.0], [-0.2, -0.1], [-289.5, 577.9], [0.0, 0.0], [-0.0, 0.0],
+                     [np.nan, 1.0], [1.0, np.nan], [np.inf, 0.0], [0.0, -np.inf], [1e-40, -1e-40], [16777216.0, 3.0], [3.4e38, -3.4e38]],
+                    dtype=np.float32)
+    xy = np.concatenate(parts + [edge]).astype(np.float32)
+    x, y = np.ascontiguousarray(xy[:, 0]), np.ascontiguousarray(xy[:, 1])
+    got, want = game.device_eval("simplex2d_lut", x, y), game.device_eval("simplex2d", x, y)
+    same = (_bits(got) == _bits(want)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), (xy[~same][:5], got[~same][:5], want[~same][:5])
+
+
 def test_unorm8_to_float_equals_division_for_all_bytes(game):
     b = np.arange(256, dtype=np.float32)
     assert np.array_equal(_bits(game.device_eval("unorm8", b)), _bits(b / np.float32(255.0)))
