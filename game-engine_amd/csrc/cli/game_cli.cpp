@@ -9,6 +9,8 @@
 //                                        browser): renders N frames with u_time = k / F on the GPU; with
 //                                        --out writes PREFIX_00000.ppm ... (binary P6, RGB of the RGBA8 frame),
 //                                        or PREFIX_00000.png (8-bit RGBA, stored deflate blocks) with --png;
+//                                        --out - writes the frames as raw RGBA8 to stdout, top row first (for a pipe
+//                                        into an encoder, e.g. ffmpeg -f rawvideo -pix_fmt rgba -s WxH -r FPS -i -);
 //                                        the cinematic's arc timeline (runtime/arc.rs) drives its parameters unless
 //                                        --no-arcs; --animate evaluates expression-valued stage arguments per frame
 //                                        (the reference's emitters use the parameter defaults) and runs `~` modulation
@@ -52,7 +54,7 @@ int usage()
     fprintf(stderr,
             "usage: game check FILE...\n"
             "       game render FILE --hip [--size WxH] [--frames N] [--fps F] [--batch B] [--device D]\n"
-            "                   [--cinematic I] [--out PREFIX] [--particles N --steps S]\n"
+            "                   [--cinematic I] [--out PREFIX|-] [--particles N --steps S]\n"
             "                   [--png] [--semantics glsl|wgsl] [--no-arcs] [--animate] [--lens-post] [--imports] [--lib DIR]...\n"
             "       game compare A B [--threshold T]\n"
             "       game ir FILE | game kernel FILE [--size WxH] | game builtins\n");
@@ -377,9 +379,13 @@ int cmd_render(const Args& a)
             game_hip_last_kernel_ms(ctx, &ms, &launches);
             device_ms += ms;
             for (uint32_t k = 0; k < n && !host.empty(); ++k) {
+                const uint8_t* frame = host.data() + (size_t)k * a.w * a.h * 4;
+                if (a.out == "-") {   // raw RGBA8 frames, top row first, back to back: pipe into an encoder
+                    if (fwrite(frame, 1, (size_t)a.w * a.h * 4, stdout) != (size_t)a.w * a.h * 4) { fprintf(stderr, "game render: short write to stdout\n"); ok = false; break; }
+                    continue;
+                }
                 char name[32];
                 snprintf(name, sizeof name, a.png ? "_%05u.png" : "_%05u.ppm", done + k);
-                const uint8_t* frame = host.data() + (size_t)k * a.w * a.h * 4;
                 if (!(a.png ? write_png(a.out + name, frame, a.w, a.h) : write_ppm(a.out + name, frame, a.w, a.h))) {
                     fprintf(stderr, "game render: cannot write %s%s\n", a.out.c_str(), name);
                     ok = false;
@@ -387,6 +393,7 @@ int cmd_render(const Args& a)
                 }
             }
         }
+        if (a.out == "-") fflush(stdout);
         if (!ok || game_hip_sync(ctx) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
         double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         double px = (double)a.frames * a.w * a.h;

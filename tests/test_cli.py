@@ -147,3 +147,39 @@ def test_render_animate_runs_modulation_and_expression_arguments(tmp_path, game)
         frames.append(np.frombuffer(data[len(header):], dtype=np.uint8).reshape(64, 96, 3))
         assert np.array_equal(frames[k], want[k][..., :3])
     assert not np.array_equal(frames[0], frames[3])
+
+
+@pytest.mark.gpu
+def test_render_raw_frames_to_stdout(tmp_path, game):
+    """`--out -` writes the frames as raw RGBA8 to stdout (the form an external encoder takes from a pipe)."""
+    f = tmp_path / "g.game"
+    f.write_text(C4_TRAILS)
+    r = subprocess.run([GAME, "render", str(f), "--hip", "--size", "64x36", "--frames", "3", "--fps", "30", "--out", "-"],
+                       capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert len(r.stdout) == 3 * 64 * 36 * 4
+    cin = game.compile(C4_TRAILS).cinematics[0]
+    rd = cin.renderer(64, 36)
+    want = rd.render(cin.uniform_rows([k / 30.0 for k in range(3)], 64, 36))
+    rd.close()
+    assert np.array_equal(np.frombuffer(r.stdout, dtype=np.uint8).reshape(3, 36, 64, 4), want)
+
+
+@pytest.mark.gpu
+def test_render_with_imports_and_lens_post(tmp_path, game):
+    (tmp_path / "lib.game").write_text('cinematic "lib" { define orb(size) { circle(size) | glow(2.0) } }')
+    src = 'import "lib" expose orb\ncinematic "m" { layer a { fn: orb(0.25) | tint(1.0, 0.6, 0.2) }\n lens { post: vignette(0.4, 0.7) | grain(0.02) } }'
+    f = tmp_path / "m.game"
+    f.write_text(src)
+    out = str(tmp_path / "o")
+    r = run("render", str(f), "--hip", "--size", "64x36", "--frames", "1")
+    assert r.returncode == 1 and "unknown stage function: 'orb'" in r.stderr          # imports are opt-in
+    r = run("render", str(f), "--hip", "--imports", "--lens-post", "--size", "64x36", "--frames", "1", "--out", out)
+    assert r.returncode == 0, r.stderr
+    cin = game.compile_file(str(f)).cinematics[0]
+    rd = cin.renderer(64, 36, lens_post=True)
+    want = rd.render(cin.uniform_rows([0.0], 64, 36))
+    rd.close()
+    data = open(out + "_00000.ppm", "rb").read()
+    header = b"P6\n64 36\n255\n"
+    assert np.array_equal(np.frombuffer(data[len(header):], dtype=np.uint8).reshape(36, 64, 3), want[0][..., :3])
