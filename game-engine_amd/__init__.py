@@ -60,6 +60,7 @@ def _load():
         "game_ir_frame_floats": (u32, [vp]),
         "game_ir_default_uniforms": (None, [vp, f32, u32, u32, vp]),
         "game_ir_derived_count": (u32, [vp]),
+        "game_ir_pixel_expr_count": (u32, [vp]),
         "game_ir_eval_derived": (None, [vp, vp, vp]),
         "game_animator_create": (c.c_int, [vp, c.c_double, c.POINTER(vp)]),
         "game_animator_destroy": (None, [vp]),
@@ -189,6 +190,11 @@ class Cinematic:
     def derived_count(self):
         """Number of expression-valued stage arguments kept as per-frame programs."""
         return lib.game_ir_derived_count(self._h)
+
+    @property
+    def pixel_expr_count(self):
+        """Number of expression-valued stage arguments that read the pixel (evaluated inside the kernel)."""
+        return lib.game_ir_pixel_expr_count(self._h)
 
     def eval_derived(self, rows):
         """Per-frame values of those arguments for an (n, frame_floats) float32 array of uniform rows."""

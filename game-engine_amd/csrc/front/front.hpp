@@ -217,7 +217,9 @@ enum IrFlag : uint32_t {
 // derived >= 0: the source wrote an expression here. The reference's emitters drop it for the parameter's
 // default (kind/slot/lit above hold that); a context created with GAME_HIP_ANIMATE_ARGS instead evaluates
 // Ir::derived[derived] on the host once per frame and passes the value as an extra uniform.
-struct IrArg { uint32_t kind = ARG_LIT; uint32_t slot = 0; float lit = 0.0f; std::string text; int derived = -1; };
+// pixel >= 0: the expression also reads the pixel (`p.x`, `p.y`, `uv.x`, `uv.y`); such a context evaluates
+// Ir::pixel_exprs[pixel] inside the kernel, in f32 with the device functions, where the stage runs.
+struct IrArg { uint32_t kind = ARG_LIT; uint32_t slot = 0; float lit = 0.0f; std::string text; int derived = -1; int pixel = -1; };
 struct IrStage { uint16_t builtin = 0; uint32_t nargs = 0; IrArg args[4]; uint32_t aux = 0; std::string name; };
 struct IrLayer {
     std::string name;
@@ -228,7 +230,7 @@ struct IrLayer {
     bool post = false;   // the lens post chain: runs on the composited colour, only when the renderer is asked to
 };
 enum LawOp : uint32_t { LAW_NUM = 0, LAW_DIST, LAW_TIME, LAW_ADD, LAW_SUB, LAW_MUL, LAW_DIV, LAW_POW, LAW_GT, LAW_LT,
-                        LAW_NEG, LAW_CALL1, LAW_CALL2, LAW_CALL3, LAW_UNIFORM };
+                        LAW_NEG, LAW_CALL1, LAW_CALL2, LAW_CALL3, LAW_UNIFORM, LAW_PX, LAW_PY, LAW_UVX, LAW_UVY };
 enum LawFn : uint32_t { LF_SIN = 0, LF_COS, LF_TAN, LF_ABS, LF_SQRT, LF_EXP, LF_LOG, LF_FLOOR, LF_CEIL, LF_FRACT, LF_SIGN,
                         LF_MIN, LF_MAX, LF_POW, LF_STEP, LF_CLAMP, LF_MIX, LF_SMOOTHSTEP, LF_EXP2, LF_LOG2, LF_COUNT };
 struct IrLawOp { uint32_t op = LAW_NUM; float val = 0.0f; uint32_t fn = 0; };
@@ -272,6 +274,7 @@ struct Ir {
     bool uses_memory = false;
     std::vector<IrArc> arcs;
     std::vector<IrDerived> derived;
+    std::vector<IrDerived> pixel_exprs;   // programs that also use LAW_PX / LAW_PY / LAW_UVX / LAW_UVY
     std::vector<IrParamAnim> anims;
     std::vector<IrResonance> resonances;
 };

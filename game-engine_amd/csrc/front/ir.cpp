@@ -134,7 +134,7 @@ std::string expr_source_text(const Expr& e)
 
 // Frame-level scalar expression -> RPN; false when it reads something that is not a frame constant
 // (`p`, `uv`, an unknown name, a string, an array) or calls an unknown function.
-bool lower_frame_expr(const Expr& e, const std::map<std::string, uint32_t>& uslot, std::vector<IrLawOp>& prog)
+bool lower_frame_expr(const Expr& e, const std::map<std::string, uint32_t>& uslot, std::vector<IrLawOp>& prog, bool allow_pixel = false)
 {
     auto push = [&](uint32_t op, float v = 0.0f, uint32_t fn = 0) { IrLawOp o; o.op = op; o.val = v; o.fn = fn; prog.push_back(o); };
     switch (e.kind) {
@@ -155,12 +155,16 @@ bool lower_frame_expr(const Expr& e, const std::map<std::string, uint32_t>& uslo
             {"audio", "bass", BU_AUDIO_BASS}, {"audio", "mid", BU_AUDIO_MID}, {"audio", "treble", BU_AUDIO_TREBLE},
             {"audio", "energy", BU_AUDIO_ENERGY}, {"audio", "beat", BU_AUDIO_BEAT}, {"mouse", "x", BU_MOUSE_X}, {"mouse", "y", BU_MOUSE_Y}};
         for (auto& d : dotted) if (e.s == d.o && e.field == d.f) { push(LAW_UNIFORM, 0.0f, d.slot); return true; }
+        if (allow_pixel && (e.s == "p" || e.s == "uv") && (e.field == "x" || e.field == "y")) {
+            push(e.s == "p" ? (e.field == "x" ? LAW_PX : LAW_PY) : (e.field == "x" ? LAW_UVX : LAW_UVY));
+            return true;
+        }
         return false;
     }
-    case Expr::Paren: return lower_frame_expr(e.kids[0], uslot, prog);
-    case Expr::Neg: if (!lower_frame_expr(e.kids[0], uslot, prog)) return false; push(LAW_NEG); return true;
+    case Expr::Paren: return lower_frame_expr(e.kids[0], uslot, prog, allow_pixel);
+    case Expr::Neg: if (!lower_frame_expr(e.kids[0], uslot, prog, allow_pixel)) return false; push(LAW_NEG); return true;
     case Expr::Bin: {
-        if (!lower_frame_expr(e.kids[0], uslot, prog) || !lower_frame_expr(e.kids[1], uslot, prog)) return false;
+        if (!lower_frame_expr(e.kids[0], uslot, prog, allow_pixel) || !lower_frame_expr(e.kids[1], uslot, prog, allow_pixel)) return false;
         static const uint32_t ops[] = {LAW_ADD, LAW_SUB, LAW_MUL, LAW_DIV, LAW_POW, LAW_GT, LAW_LT};
         push(ops[(int)e.op]);
         return true;
@@ -169,7 +173,7 @@ bool lower_frame_expr(const Expr& e, const std::map<std::string, uint32_t>& uslo
         bool ok;
         LawFn f = law_fn(e.s, e.args.size(), ok);
         if (!ok) return false;
-        for (const Arg& a : e.args) if (!lower_frame_expr(a.value, uslot, prog)) return false;
+        for (const Arg& a : e.args) if (!lower_frame_expr(a.value, uslot, prog, allow_pixel)) return false;
         push(e.args.size() == 1 ? LAW_CALL1 : e.args.size() == 2 ? LAW_CALL2 : LAW_CALL3, 0.0f, f);
         return true;
     }
@@ -379,10 +383,17 @@ Ir lower_cinematic(const Cinematic& c)
             // (not for palette names or the fbm octave count, which must stay compile-time values)
             if (t.dropped && b->id != B_PALETTE && !(b->id == B_FBM && p == 1)) {
                 IrDerived d;
-                if (lower_frame_expr(*t.dropped, uslot, d.prog) && d.prog.size() < 48) {
+                if (lower_frame_expr(*t.dropped, uslot, d.prog) && d.prog.size() < 48 && ir.derived.size() < 0xfffe) {
                     d.text = expr_source_text(*t.dropped);
                     a.derived = (int)ir.derived.size();
                     ir.derived.push_back(std::move(d));
+                } else {
+                    d.prog.clear();   // not a frame constant: maybe a function of the pixel as well
+                    if (lower_frame_expr(*t.dropped, uslot, d.prog, true) && d.prog.size() < 48 && ir.pixel_exprs.size() < 0xfffe) {
+                        d.text = expr_source_text(*t.dropped);
+                        a.pixel = (int)ir.pixel_exprs.size();
+                        ir.pixel_exprs.push_back(std::move(d));
+                    }
                 }
             }
         }
@@ -694,7 +705,8 @@ std::vector<uint8_t> ir_serialize(const Ir& ir)
             put_u32(b, s.args[i].kind);
             put_u32(b, s.args[i].slot);
             put_f32(b, s.args[i].lit);
-            put_u32(b, (uint32_t)(s.args[i].derived + 1));   // 0 = none, else index + 1 into the derived values
+            // low half: index + 1 into the derived values, high half: index + 1 into the pixel expressions (0 = none)
+            put_u32(b, (uint32_t)(s.args[i].derived + 1) | ((uint32_t)(s.args[i].pixel + 1) << 16));
         }
     }
     for (const UniformInfo& u : ir.uniforms) {
@@ -706,6 +718,17 @@ std::vector<uint8_t> ir_serialize(const Ir& ir)
         put_f32(b, o.val);
         put_u32(b, o.fn);
         put_u32(b, 0);
+    }
+    // trailing section: the pixel-expression programs
+    put_u32(b, (uint32_t)ir.pixel_exprs.size());
+    for (const IrDerived& d : ir.pixel_exprs) {
+        put_u32(b, (uint32_t)d.prog.size());
+        for (const IrLawOp& o : d.prog) {
+            put_u32(b, o.op);
+            put_f32(b, o.val);
+            put_u32(b, o.fn);
+            put_u32(b, 0);
+        }
     }
     uint32_t total = (uint32_t)b.size();
     for (int i = 0; i < 4; ++i) b[4 + i] = (uint8_t)(total >> (8 * i));
@@ -743,7 +766,7 @@ std::string ir_to_json(const Ir& ir)
                 const IrArg& ia = s.args[a];
                 const char* kind = ia.kind == ARG_LIT ? "lit" : ia.kind == ARG_USER ? "user" : "builtin";
                 j += "{\"kind\":\"" + std::string(kind) + "\",\"slot\":" + std::to_string(ia.slot) + ",\"lit\":" + f32_json(ia.lit) +
-                     ",\"text\":\"" + json_escape(ia.text) + "\",\"derived\":" + std::to_string(ia.derived) + "}";
+                     ",\"text\":\"" + json_escape(ia.text) + "\",\"derived\":" + std::to_string(ia.derived) + ",\"pixel\":" + std::to_string(ia.pixel) + "}";
             }
             j += "]}";
         }
@@ -758,6 +781,9 @@ std::string ir_to_json(const Ir& ir)
     }
     j += ",\"derived\":[";
     for (size_t i = 0; i < ir.derived.size(); ++i) j += (i ? ",\"" : "\"") + json_escape(ir.derived[i].text) + "\"";
+    j += "]";
+    j += ",\"pixel_exprs\":[";
+    for (size_t i = 0; i < ir.pixel_exprs.size(); ++i) j += (i ? ",\"" : "\"") + json_escape(ir.pixel_exprs[i].text) + "\"";
     j += "]";
     j += ",\"anims\":[";
     for (size_t i = 0; i < ir.anims.size(); ++i) {

@@ -22,10 +22,58 @@ std::string float_literal(float v)
 
 namespace {
 
+// Reverse Polish program -> one HIP expression over the device functions (f32, one rounding per operator).
+// gravity = true: the force law of a gravity block (variables `dist` and the simulation time, gravity.rs:10-41);
+// otherwise a stage-argument expression that reads the pixel (`p`, `uv`) and the frame row.
+std::string rpn_expr(const std::vector<IrLawOp>& prog, bool gravity)
+{
+    static const char* fn1[] = {"gd_sin", "gd_cos", "gd_tan", "gd_abs", "gd_sqrt", "gd_exp", "gd_log", "gd_floor", "gd_ceil",
+                                "gd_fract", "gd_sign", "", "", "", "", "", "", "", "gd_exp2", "gd_log2"};
+    std::vector<std::string> st;
+    if (prog.empty()) return "1.0f";
+    for (const IrLawOp& o : prog) {
+        auto pop = [&]() { std::string t = st.back(); st.pop_back(); return t; };
+        switch (o.op) {
+        case LAW_NUM: st.push_back(float_literal(o.val)); break;
+        case LAW_DIST: st.push_back("dist"); break;
+        case LAW_TIME: st.push_back("P.time"); break;
+        case LAW_UNIFORM: st.push_back(!gravity && o.fn == BU_TIME ? std::string("s.time") : "U[" + std::to_string(o.fn) + "]"); break;
+        case LAW_PX: st.push_back("s.px"); break;
+        case LAW_PY: st.push_back("s.py"); break;
+        case LAW_UVX: st.push_back("s.uvx"); break;
+        case LAW_UVY: st.push_back("s.uvy"); break;
+        case LAW_ADD: { auto r = pop(), l = pop(); st.push_back("(" + l + " + " + r + ")"); break; }
+        case LAW_SUB: { auto r = pop(), l = pop(); st.push_back("(" + l + " - " + r + ")"); break; }
+        case LAW_MUL: { auto r = pop(), l = pop(); st.push_back("(" + l + " * " + r + ")"); break; }
+        case LAW_DIV: { auto r = pop(), l = pop(); st.push_back("(" + l + " / " + r + ")"); break; }
+        case LAW_POW: { auto r = pop(), l = pop(); st.push_back("gd_pow(" + l + ", " + r + ")"); break; }
+        case LAW_GT: { auto r = pop(), l = pop(); st.push_back("((" + l + " > " + r + ") ? 1.0f : 0.0f)"); break; }
+        case LAW_LT: { auto r = pop(), l = pop(); st.push_back("((" + l + " < " + r + ") ? 1.0f : 0.0f)"); break; }
+        case LAW_NEG: { auto v = pop(); st.push_back("(-" + v + ")"); break; }
+        case LAW_CALL1: { auto v = pop(); st.push_back(std::string(fn1[o.fn]) + "(" + v + ")"); break; }
+        case LAW_CALL2: {
+            auto b = pop(), a = pop();
+            const char* f = o.fn == LF_MIN ? "gd_min" : o.fn == LF_MAX ? "gd_max" : o.fn == LF_POW ? "gd_pow" : "gd_step";
+            st.push_back(std::string(f) + "(" + a + ", " + b + ")");
+            break;
+        }
+        case LAW_CALL3: {
+            auto c = pop(), b = pop(), a = pop();
+            const char* f = o.fn == LF_CLAMP ? "gd_clamp" : o.fn == LF_MIX ? "gd_mix" : "gd_smoothstep";
+            st.push_back(std::string(f) + "(" + a + ", " + b + ", " + c + ")");
+            break;
+        }
+        default: break;
+        }
+    }
+    return st.empty() ? "1.0f" : st.back();
+}
+
 // Frame-row layout used by the kernels: the caller's 10 + n floats, then two derived values the
 // host computes once per frame (glsl.rs:55-56), then (animate shapes only) one float per derived value.
-std::string arg_expr(const IrArg& a, const KernelShape& shape)
+std::string arg_expr(const IrArg& a, const KernelShape& shape, const Ir& ir)
 {
+    if (shape.animate && a.pixel >= 0) return rpn_expr(ir.pixel_exprs[(size_t)a.pixel].prog, false);
     if (shape.animate && a.derived >= 0) return "U[" + std::to_string(shape.derived_slot + (uint32_t)a.derived) + "]";
     switch (a.kind) {
     case ARG_LIT: return float_literal(a.lit);
@@ -65,10 +113,10 @@ bool has_wgsl_variant(uint16_t b)
     }
 }
 
-std::string stage_call(const IrStage& st, const KernelShape& shape)
+std::string stage_call(const IrStage& st, const KernelShape& shape, const Ir& ir)
 {
     const bool wgsl = shape.wgsl;
-    auto A = [&](int i) { return arg_expr(st.args[i], shape); };
+    auto A = [&](int i) { return arg_expr(st.args[i], shape, ir); };
     auto call = [&](const char* fn, int n) {
         std::string name(fn);
         if (wgsl && has_wgsl_variant(st.builtin)) name[1] = 'w';   // gb_xxx -> gw_xxx
@@ -215,7 +263,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
             k += "    {   // lens post\n";
             k += "        s.px = s.uvx * aspect; s.py = s.uvy; s.sdf = 0.0f; s.r = fr; s.g = fg; s.b = fb; s.a = fa;\n";
             for (uint32_t si = 0; si < L.stage_count; ++si)
-                k += "        " + stage_call(ir.stages[L.stage_begin + si], shape) + "\n";
+                k += "        " + stage_call(ir.stages[L.stage_begin + si], shape, ir) + "\n";
             k += "        fr = s.r; fg = s.g; fb = s.b; fa = s.a;\n";
             k += "    }\n";
             continue;
@@ -223,7 +271,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
         k += "    {   // layer " + std::to_string(li) + "\n";
         k += "        s.px = s.uvx * aspect; s.py = s.uvy; s.sdf = 0.0f; s.r = s.g = s.b = s.a = 0.0f;\n";
         for (uint32_t si = 0; si < L.stage_count; ++si)
-            k += "        " + stage_call(ir.stages[L.stage_begin + si], shape) + "\n";
+            k += "        " + stage_call(ir.stages[L.stage_begin + si], shape, ir) + "\n";
         if (L.has_memory) k += "        gb_memory_mix(s, prev, " + float_literal(L.decay) + ");\n";
         if (ir.multi_layer) {
             k += "        fr = fr + s.r - fr * s.r; fg = fg + s.g - fg * s.g; fb = fb + s.b - fb * s.b; fa = 1.0f;\n";
@@ -252,45 +300,6 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
 // ── gravity ──────────────────────────────────────────────────────────────────────────────
 namespace {
 
-std::string law_expr(const Ir& ir)
-{
-    static const char* fn1[] = {"gd_sin", "gd_cos", "gd_tan", "gd_abs", "gd_sqrt", "gd_exp", "gd_log", "gd_floor", "gd_ceil",
-                                "gd_fract", "gd_sign", "", "", "", "", "", "", "", "gd_exp2", "gd_log2"};
-    std::vector<std::string> st;
-    if (ir.gravity.law.empty()) return "1.0f";
-    for (const IrLawOp& o : ir.gravity.law) {
-        auto pop = [&]() { std::string t = st.back(); st.pop_back(); return t; };
-        switch (o.op) {
-        case LAW_NUM: st.push_back(float_literal(o.val)); break;
-        case LAW_DIST: st.push_back("dist"); break;
-        case LAW_TIME: st.push_back("P.time"); break;
-        case LAW_ADD: { auto r = pop(), l = pop(); st.push_back("(" + l + " + " + r + ")"); break; }
-        case LAW_SUB: { auto r = pop(), l = pop(); st.push_back("(" + l + " - " + r + ")"); break; }
-        case LAW_MUL: { auto r = pop(), l = pop(); st.push_back("(" + l + " * " + r + ")"); break; }
-        case LAW_DIV: { auto r = pop(), l = pop(); st.push_back("(" + l + " / " + r + ")"); break; }
-        case LAW_POW: { auto r = pop(), l = pop(); st.push_back("gd_pow(" + l + ", " + r + ")"); break; }
-        case LAW_GT: { auto r = pop(), l = pop(); st.push_back("((" + l + " > " + r + ") ? 1.0f : 0.0f)"); break; }
-        case LAW_LT: { auto r = pop(), l = pop(); st.push_back("((" + l + " < " + r + ") ? 1.0f : 0.0f)"); break; }
-        case LAW_NEG: { auto v = pop(); st.push_back("(-" + v + ")"); break; }
-        case LAW_CALL1: { auto v = pop(); st.push_back(std::string(fn1[o.fn]) + "(" + v + ")"); break; }
-        case LAW_CALL2: {
-            auto b = pop(), a = pop();
-            const char* f = o.fn == LF_MIN ? "gd_min" : o.fn == LF_MAX ? "gd_max" : o.fn == LF_POW ? "gd_pow" : "gd_step";
-            st.push_back(std::string(f) + "(" + a + ", " + b + ")");
-            break;
-        }
-        case LAW_CALL3: {
-            auto c = pop(), b = pop(), a = pop();
-            const char* f = o.fn == LF_CLAMP ? "gd_clamp" : o.fn == LF_MIX ? "gd_mix" : "gd_smoothstep";
-            st.push_back(std::string(f) + "(" + a + ", " + b + ", " + c + ")");
-            break;
-        }
-        default: break;
-        }
-    }
-    return st.empty() ? "1.0f" : st.back();
-}
-
 }  // namespace
 
 std::string generate_gravity_kernel(const Ir& ir)
@@ -299,8 +308,7 @@ std::string generate_gravity_kernel(const Ir& ir)
     k += "// generated gravity step for cinematic \"" + ir.name + "\"\n";
     k += "#include \"game_device.h\"\n\n";
     k += "#ifndef GD_GRAV_UNROLL\n#define GD_GRAV_UNROLL 8\n#endif\n";
-    k += "GD float gd_ceil(float x) { return -gd_floor(-x); }\n";
-    k += "GD float gd_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }\n\n";
+    k += "\n";
     k += "struct GameGravityParams {\n"
          "    const float* xin; const float* yin;\n"
          "    float* xout; float* yout; float* vx; float* vy;\n"
@@ -340,7 +348,7 @@ std::string generate_gravity_kernel(const Ir& ir)
             b += "                const float inv = rinv;\n";
         }
         b += "                const float dirx = dx * inv, diry = dy * inv;\n";
-        b += "                const float f = " + law_expr(ir) + ";\n";
+        b += "                const float f = " + rpn_expr(ir.gravity.law, true) + ";\n";
         if (check_self) {
             b += "                const bool self = (base + t) == idx;\n";
             b += "                fx = self ? fx : __builtin_fmaf(dirx, f, fx);\n";

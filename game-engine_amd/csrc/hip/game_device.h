@@ -94,6 +94,8 @@ GD float gd_rcp(float y)
 }
 GD float gd_mod(float x, float y) { return x - y * gd_floor(x * gd_rcp(y)); }
 GD float gd_step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
+GD float gd_ceil(float x) { return -gd_floor(-x); }
+GD float gd_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 GD float gd_mix(float a, float b, float t) { return __builtin_fmaf(b, t, a * (1.0f - t)); }
 GD float gd_smoothstep(float e0, float e1, float x)
 {

@@ -169,7 +169,7 @@ KernelShape shape_for(const Ir& ir, uint32_t width, uint32_t flags = 0)
     uint32_t row = BU_COUNT + (uint32_t)ir.uniforms.size();
     s.time_slot = row;
     s.aspect_slot = row + 1;
-    s.animate = (flags & GAME_HIP_ANIMATE_ARGS) != 0 && !ir.derived.empty();
+    s.animate = (flags & GAME_HIP_ANIMATE_ARGS) != 0 && (!ir.derived.empty() || !ir.pixel_exprs.empty());
     s.derived_slot = row + 2;
     s.lens_post = (flags & GAME_HIP_LENS_POST) != 0;
     return s;

@@ -109,8 +109,13 @@ void game_ir_default_uniforms(const game_ir* ir, float time_s, uint32_t w, uint3
  * only frame constants (numbers, pi/tau/e/phi, `time`, audio.*, mouse.*, user uniforms; + - * / ^ > <, the
  * scalar math functions) as a "derived value". game_ir_eval_derived computes them for one frame row in f32;
  * a context created with GAME_HIP_ANIMATE_ARGS does so itself for every frame and feeds them to the kernel
- * as extra uniforms. Without that flag the defaults are used, as the reference does. */
+ * as extra uniforms. Without that flag the defaults are used, as the reference does.
+ * An expression that also reads the pixel (`p.x`, `p.y`, `uv.x`, `uv.y`: `circle(0.2 + 0.05 * sin(p.x * 20.0))`)
+ * cannot be a frame constant; the IR keeps it as a "pixel expression" (game_ir_pixel_expr_count) and a context
+ * with GAME_HIP_ANIMATE_ARGS evaluates it inside the kernel, in f32 with the device functions, at the point
+ * where its stage runs (`p` is the position the earlier stages of the layer have produced). */
 uint32_t game_ir_derived_count(const game_ir* ir);
+uint32_t game_ir_pixel_expr_count(const game_ir* ir);
 void game_ir_eval_derived(const game_ir* ir, const float* row, float* out /* game_ir_derived_count floats */);
 
 /* Host-side animation of the user uniforms, one call per frame, in frame order. The reference emits this as
@@ -155,11 +160,14 @@ enum {
  *            multi_layer, uses_memory, gravity_present, gravity_damping(f32), gravity_bounds
  *            (0 reflect, 1 wrap, 2 none), name[64]
  *   layer  : is_pipeline, stage_begin, stage_count, has_memory, decay(f32), end_state
- *            (0 Position, 1 Sdf, 2 Color), 0, 0                                   (32 bytes)
- *   stage  : builtin_id, nargs, aux(palette index), 0, then 4 x {kind, slot, lit(f32), derived index + 1 or 0}
- *            kind 0 = literal, 1 = user uniform slot, 2 = built-in uniform slot   (80 bytes)
+ *            (0 Position, 1 Sdf, 2 Color), post (1 = the lens post chain), 0      (32 bytes)
+ *   stage  : builtin_id, nargs, aux(palette index), 0, then 4 x {kind, slot, lit(f32), expr}
+ *            kind 0 = literal, 1 = user uniform slot, 2 = built-in uniform slot;
+ *            expr = (derived index + 1) | (pixel expression index + 1) << 16, 0 = none      (80 bytes)
  *   uniform: default(f32), name[60]                                               (64 bytes)
  *   law op : op, value(f32), fn, 0                                                (16 bytes)
+ *   then   : n_pixel_expressions, and per expression its length and that many law ops (ops 14..18 push a frame-row
+ *            slot (fn), p.x, p.y, uv.x, uv.y)
  * Built-in uniform slot 0 used as a stage argument means the shader's wrapped time
  * `fract(u_time / 120) * 120` (glsl.rs:56), not the raw u_time. */
 

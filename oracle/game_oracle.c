@@ -42,11 +42,15 @@ typedef struct {
     float damping; uint32_t bounds; char name[64];
 } ir_header;
 
+#define MAX_PIXEL_EXPRS 256
 typedef struct {
     const ir_header* h;
     const ir_layer* layers;
     const ir_stage* stages;
     const ir_law* law;
+    uint32_t n_pix;                              /* stage-argument expressions that read the pixel */
+    const ir_law* pix[MAX_PIXEL_EXPRS];
+    uint32_t pix_len[MAX_PIXEL_EXPRS];
 } ir_view;
 
 static int ir_open(const void* blob, size_t len, ir_view* v)
@@ -56,13 +60,24 @@ static int ir_open(const void* blob, size_t len, ir_view* v)
     if (h->magic != 0x31524947u || h->total != len) return -1;
     size_t need = sizeof(ir_header) + (size_t)h->n_layers * sizeof(ir_layer) + (size_t)h->n_stages * sizeof(ir_stage) +
                   (size_t)h->n_uniforms * 64 + (size_t)h->n_law * sizeof(ir_law);
-    if (need != len) return -1;
+    if (need + 4 > len) return -1;
     const char* p = (const char*)blob + sizeof(ir_header);
     v->h = h;
     v->layers = (const ir_layer*)p; p += (size_t)h->n_layers * sizeof(ir_layer);
     v->stages = (const ir_stage*)p; p += (size_t)h->n_stages * sizeof(ir_stage);
     p += (size_t)h->n_uniforms * 64;
-    v->law = (const ir_law*)p;
+    v->law = (const ir_law*)p; p += (size_t)h->n_law * sizeof(ir_law);
+    /* trailing section: count, then per program its length and operations */
+    const char* end = (const char*)blob + len;
+    memcpy(&v->n_pix, p, 4); p += 4;
+    if (v->n_pix > MAX_PIXEL_EXPRS) return -1;
+    for (uint32_t i = 0; i < v->n_pix; i++) {
+        if (p + 4 > end) return -1;
+        memcpy(&v->pix_len[i], p, 4); p += 4;
+        if (v->pix_len[i] > 64 || p + (size_t)v->pix_len[i] * sizeof(ir_law) > end) return -1;
+        v->pix[i] = (const ir_law*)p; p += (size_t)v->pix_len[i] * sizeof(ir_law);
+    }
+    if (p != end) return -1;
     return 0;
 }
 
@@ -198,11 +213,85 @@ typedef struct {
     const float* row;/* this frame's uniform row: 10 built-ins then user uniforms */
     const float* derived; /* per-frame values of expression-valued arguments, or NULL: the reference's behaviour
                              (stages.rs:8-22 substitutes the parameter default, which kind/slot/lit hold) */
+    int animate;     /* expression-valued arguments are live: frame-level ones read `derived`, those that also
+                        read the pixel are evaluated here, in f32, where the stage runs */
 } frame_consts;
 
-static inline float arg_value(const ir_arg* a, const frame_consts* fc)
+enum { LAW_NUM = 0, LAW_DIST, LAW_TIME, LAW_ADD, LAW_SUB, LAW_MUL, LAW_DIV, LAW_POW, LAW_GT, LAW_LT, LAW_NEG,
+       LAW_CALL1, LAW_CALL2, LAW_CALL3, LAW_UNIFORM, LAW_PX, LAW_PY, LAW_UVX, LAW_UVY };
+enum { LF_SIN = 0, LF_COS, LF_TAN, LF_ABS, LF_SQRT, LF_EXP, LF_LOG, LF_FLOOR, LF_CEIL, LF_FRACT, LF_SIGN,
+       LF_MIN, LF_MAX, LF_POW, LF_STEP, LF_CLAMP, LF_MIX, LF_SMOOTHSTEP, LF_EXP2, LF_LOG2 };
+
+static float law_call(uint32_t fn, float a, float b, float c)
 {
-    if (fc->derived && a->pad) return fc->derived[a->pad - 1];   /* pad = derived index + 1 */
+    switch (fn) {
+    case LF_SIN: return gm_sin(a); case LF_COS: return gm_cos(a); case LF_TAN: return gm_tan(a);
+    case LF_ABS: return gm_abs(a); case LF_SQRT: return sqrtf(a); case LF_EXP: return gm_exp(a);
+    case LF_LOG: return gm_log(a); case LF_FLOOR: return gm_floor(a); case LF_CEIL: return -gm_floor(-a);
+    case LF_FRACT: return gm_fract(a); case LF_SIGN: return a > 0.0f ? 1.0f : (a < 0.0f ? -1.0f : 0.0f);
+    case LF_EXP2: return gm_exp2(a); case LF_LOG2: return gm_log2(a);
+    case LF_MIN: return gm_min(a, b); case LF_MAX: return gm_max(a, b); case LF_POW: return gm_pow(a, b);
+    case LF_STEP: return gm_step(a, b);
+    case LF_CLAMP: return gm_clamp(a, b, c); case LF_MIX: return gm_mix(a, b, c);
+    case LF_SMOOTHSTEP: return gm_smoothstep(a, b, c);
+    default: return 0.0f;
+    }
+}
+
+/* What a reverse Polish program may read: the gravity force law uses dist and time (gravity.rs:10-41); a stage
+ * argument that reads the pixel uses the frame row (slot 0 = the wrapped time), p and uv. */
+typedef struct { float dist, time; const float* row; float wtime, px, py, uvx, uvy; } law_vars;
+
+static float eval_rpn(const ir_law* law, uint32_t n, const law_vars* V)
+{
+    float st[64];
+    int sp = 0;
+    if (n == 0) return 1.0f;
+    for (uint32_t i = 0; i < n; i++) {
+        const ir_law* o = &law[i];
+        switch (o->op) {
+        case LAW_NUM: st[sp++] = o->val; break;
+        case LAW_DIST: st[sp++] = V->dist; break;
+        case LAW_TIME: st[sp++] = V->time; break;
+        case LAW_UNIFORM: st[sp++] = o->fn == BU_TIME ? V->wtime : V->row[o->fn]; break;
+        case LAW_PX: st[sp++] = V->px; break;
+        case LAW_PY: st[sp++] = V->py; break;
+        case LAW_UVX: st[sp++] = V->uvx; break;
+        case LAW_UVY: st[sp++] = V->uvy; break;
+        case LAW_ADD: sp--; st[sp - 1] = st[sp - 1] + st[sp]; break;
+        case LAW_SUB: sp--; st[sp - 1] = st[sp - 1] - st[sp]; break;
+        case LAW_MUL: sp--; st[sp - 1] = st[sp - 1] * st[sp]; break;
+        case LAW_DIV: sp--; st[sp - 1] = st[sp - 1] / st[sp]; break;
+        case LAW_POW: sp--; st[sp - 1] = gm_pow(st[sp - 1], st[sp]); break;
+        case LAW_GT: sp--; st[sp - 1] = st[sp - 1] > st[sp] ? 1.0f : 0.0f; break;
+        case LAW_LT: sp--; st[sp - 1] = st[sp - 1] < st[sp] ? 1.0f : 0.0f; break;
+        case LAW_NEG: st[sp - 1] = -st[sp - 1]; break;
+        case LAW_CALL1: st[sp - 1] = law_call(o->fn, st[sp - 1], 0.0f, 0.0f); break;
+        case LAW_CALL2: sp--; st[sp - 1] = law_call(o->fn, st[sp - 1], st[sp], 0.0f); break;
+        case LAW_CALL3: sp -= 2; st[sp - 1] = law_call(o->fn, st[sp - 1], st[sp], st[sp + 1]); break;
+        default: break;
+        }
+        if (sp >= 60) return 0.0f;
+    }
+    return st[0];
+}
+
+static float eval_law(const ir_law* law, uint32_t n, float dist, float time)
+{
+    law_vars V = {dist, time, NULL, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    return eval_rpn(law, n, &V);
+}
+
+static inline float arg_value(const ir_arg* a, const frame_consts* fc, const ir_view* ir, float px, float py, float uvx, float uvy)
+{
+    if (fc->animate && a->pad) {   /* low half: derived index + 1; high half: pixel-expression index + 1 */
+        const uint32_t pix = a->pad >> 16, der = a->pad & 0xffffu;
+        if (pix && pix <= ir->n_pix) {
+            law_vars V = {0.0f, 0.0f, fc->row, fc->time, px, py, uvx, uvy};
+            return eval_rpn(ir->pix[pix - 1], ir->pix_len[pix - 1], &V);
+        }
+        if (der && fc->derived) return fc->derived[der - 1];
+    }
     if (a->kind == 0) return a->lit;
     if (a->kind == 1) return fc->row[BU_COUNT + a->slot];
     return a->slot == BU_TIME ? fc->time : fc->row[a->slot];
@@ -395,8 +484,8 @@ static void shade_pixel(const ir_view* ir, const frame_consts* fc, float uvx, fl
         }
         for (uint32_t si = 0; si < L->stage_count; si++) {
             const ir_stage* S = &ir->stages[L->stage_begin + si];
-            const float a0 = arg_value(&S->args[0], fc), a1 = arg_value(&S->args[1], fc);
-            const float a2 = arg_value(&S->args[2], fc), a3 = arg_value(&S->args[3], fc);
+            const float a0 = arg_value(&S->args[0], fc, ir, px, py, uvx, uvy), a1 = arg_value(&S->args[1], fc, ir, px, py, uvx, uvy);
+            const float a2 = arg_value(&S->args[2], fc, ir, px, py, uvx, uvy), a3 = arg_value(&S->args[3], fc, ir, px, py, uvx, uvy);
             if (fc->wgsl) {
                 pix_state st = {px, py, sdf, cr, cg, cb, ca};
                 if (wgsl_stage(S->builtin, &st, a0, a1, a2, uvx, uvy, time)) {
@@ -666,7 +755,8 @@ int game_oracle_render(const void* blob, size_t blob_len, uint32_t w, uint32_t h
 }
 
 /* semantics, bit 0: 0 = the WebGL2 wording of every builtin (glsl.rs), 1 = the WebGPU wording where it differs
- * (wgsl.rs). Bit 2 (value 4): also run the lens post chain. */
+ * (wgsl.rs). Bit 1 (value 2): expression-valued stage arguments are live (implied by a non-NULL `derived`). Bit 2
+ * (value 4): also run the lens post chain. */
 int game_oracle_render_ex(const void* blob, size_t blob_len, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows,
                           const float* uniforms, const uint8_t* prev_rgba8, uint8_t* out_rgba8, int nthreads, int semantics)
 {
@@ -684,6 +774,7 @@ int game_oracle_render_ex2(const void* blob, size_t blob_len, uint32_t w, uint32
     frame_consts fc;
     fc.wgsl = (semantics & 1) != 0;
     fc.lens_post = (semantics & 4) != 0;
+    fc.animate = (semantics & 2) != 0 || derived != NULL;
     fc.row = uniforms;
     fc.derived = derived;
     fc.aspect = uniforms[BU_RES_X] / uniforms[BU_RES_Y];               /* glsl.rs:55 */
@@ -711,56 +802,6 @@ int game_oracle_render_ex2(const void* blob, size_t blob_len, uint32_t w, uint32
 }
 
 /* ── gravity (gravity.rs:43-120) ───────────────────────────────────────────────────────── */
-enum { LAW_NUM = 0, LAW_DIST, LAW_TIME, LAW_ADD, LAW_SUB, LAW_MUL, LAW_DIV, LAW_POW, LAW_GT, LAW_LT, LAW_NEG,
-       LAW_CALL1, LAW_CALL2, LAW_CALL3 };
-enum { LF_SIN = 0, LF_COS, LF_TAN, LF_ABS, LF_SQRT, LF_EXP, LF_LOG, LF_FLOOR, LF_CEIL, LF_FRACT, LF_SIGN,
-       LF_MIN, LF_MAX, LF_POW, LF_STEP, LF_CLAMP, LF_MIX, LF_SMOOTHSTEP, LF_EXP2, LF_LOG2 };
-
-static float law_call(uint32_t fn, float a, float b, float c)
-{
-    switch (fn) {
-    case LF_SIN: return gm_sin(a); case LF_COS: return gm_cos(a); case LF_TAN: return gm_tan(a);
-    case LF_ABS: return gm_abs(a); case LF_SQRT: return sqrtf(a); case LF_EXP: return gm_exp(a);
-    case LF_LOG: return gm_log(a); case LF_FLOOR: return gm_floor(a); case LF_CEIL: return -gm_floor(-a);
-    case LF_FRACT: return gm_fract(a); case LF_SIGN: return a > 0.0f ? 1.0f : (a < 0.0f ? -1.0f : 0.0f);
-    case LF_EXP2: return gm_exp2(a); case LF_LOG2: return gm_log2(a);
-    case LF_MIN: return gm_min(a, b); case LF_MAX: return gm_max(a, b); case LF_POW: return gm_pow(a, b);
-    case LF_STEP: return gm_step(a, b);
-    case LF_CLAMP: return gm_clamp(a, b, c); case LF_MIX: return gm_mix(a, b, c);
-    case LF_SMOOTHSTEP: return gm_smoothstep(a, b, c);
-    default: return 0.0f;
-    }
-}
-
-static float eval_law(const ir_law* law, uint32_t n, float dist, float time)   /* gravity.rs:10-41 */
-{
-    float st[64];
-    int sp = 0;
-    if (n == 0) return 1.0f;
-    for (uint32_t i = 0; i < n; i++) {
-        const ir_law* o = &law[i];
-        switch (o->op) {
-        case LAW_NUM: st[sp++] = o->val; break;
-        case LAW_DIST: st[sp++] = dist; break;
-        case LAW_TIME: st[sp++] = time; break;
-        case LAW_ADD: sp--; st[sp - 1] = st[sp - 1] + st[sp]; break;
-        case LAW_SUB: sp--; st[sp - 1] = st[sp - 1] - st[sp]; break;
-        case LAW_MUL: sp--; st[sp - 1] = st[sp - 1] * st[sp]; break;
-        case LAW_DIV: sp--; st[sp - 1] = st[sp - 1] / st[sp]; break;
-        case LAW_POW: sp--; st[sp - 1] = gm_pow(st[sp - 1], st[sp]); break;
-        case LAW_GT: sp--; st[sp - 1] = st[sp - 1] > st[sp] ? 1.0f : 0.0f; break;
-        case LAW_LT: sp--; st[sp - 1] = st[sp - 1] < st[sp] ? 1.0f : 0.0f; break;
-        case LAW_NEG: st[sp - 1] = -st[sp - 1]; break;
-        case LAW_CALL1: st[sp - 1] = law_call(o->fn, st[sp - 1], 0.0f, 0.0f); break;
-        case LAW_CALL2: sp--; st[sp - 1] = law_call(o->fn, st[sp - 1], st[sp], 0.0f); break;
-        case LAW_CALL3: sp -= 2; st[sp - 1] = law_call(o->fn, st[sp - 1], st[sp], st[sp + 1]); break;
-        default: break;
-        }
-        if (sp >= 60) return 0.0f;
-    }
-    return st[0];
-}
-
 typedef struct {
     const ir_view* ir;
     const float* in;   /* n x {pos.x, pos.y, vel.x, vel.y} */

@@ -145,3 +145,62 @@ def test_gpu_animated_memory_sequence(game, oracle):
     r.close()
     want = oracle.render_sequence(cin.blob, w, h, rows, True, derived=derived)
     assert np.array_equal(got, want)
+
+
+PIX = '''cinematic "pix" {
+  layer a { fn: rotate(p.x * 0.5) | circle(0.2 + 0.05 * sin(p.x * 20.0 + time)) | glow(1.0 + abs(uv.y)) | tint(0.5 + 0.5 * uv.x, 0.6, max(p.y, 0.2)) }
+  layer b memory: 0.8 { fn: translate(0.3, -0.2) | ring(0.25, 0.02 + 0.01 * cos(p.y * 30.0) * audio.bass) | glow(knob * (1.0 - p.x * p.x)) | tint(1.0, 0.4, 0.1)
+    knob: 1.2 }
+}'''
+
+
+def test_pixel_expressions_are_kept_apart_from_frame_expressions(game):
+    cin = game.compile(PIX).cinematics[0]
+    ir = cin.ir
+    assert cin.derived_count == 0 and cin.pixel_expr_count == 7
+    assert ir["pixel_exprs"][0] == "(p.x * 0.500000)" and ir["pixel_exprs"][-1] == "(knob * ((1.000000 - (p.x * p.x))))"
+    args = [a for l in ir["layers"] for st in l["stages"] for a in st["args"]]
+    assert [a["pixel"] for a in args if a["pixel"] >= 0] == list(range(7))
+    # things that are not scalars of the pixel stay defaults: the vector itself, unknown fields
+    for src in ('circle(p * 2.0)', 'circle(p.z)', 'circle(length(p))'):
+        c = game.compile('cinematic "a" { layer x { fn: %s | glow(1.0) } }' % src).cinematics[0]
+        assert c.pixel_expr_count == 0 and c.derived_count == 0
+
+
+def test_oracle_pixel_expressions_change_the_frame_only_when_live(game, oracle):
+    cin = game.compile(PIX).cinematics[0]
+    plain = game.compile(PIX.replace("rotate(p.x * 0.5)", "rotate(0.0)")).cinematics[0]
+    row = cin.uniform_rows([0.4], 64, 36, audio={"bass": 0.7}, user={"knob": 1.5})[0]
+    still = oracle.render(cin.blob, 64, 36, row)
+    live = oracle.render(cin.blob, 64, 36, row, animate=True)
+    assert not np.array_equal(still, live)
+    # without the flag every expression renders as its default, whatever it reads
+    prow = plain.uniform_rows([0.4], 64, 36, audio={"bass": 0.7}, user={"knob": 1.5})[0]
+    assert np.array_equal(still, oracle.render(plain.blob, 64, 36, prow))
+    # a pixel expression that happens to be constant equals the literal
+    a = game.compile('cinematic "a" { layer x { fn: circle(0.25 + p.x * 0.0) | glow(2.0) } }').cinematics[0]
+    b = game.compile('cinematic "a" { layer x { fn: circle(0.25) | glow(2.0) } }').cinematics[0]
+    r = a.uniform_rows([0.0], 48, 27)[0]
+    assert np.array_equal(oracle.render(a.blob, 48, 27, r, animate=True), oracle.render(b.blob, 48, 27, r))
+
+
+def test_pixel_expression_kernels_compile_for_gfx950(game):
+    cin = game.compile(PIX).cinematics[0]
+    assert cin.compile_only(animate=True) > 0 and cin.compile_only(semantics="wgsl", animate=True, lens_post=True) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("semantics", ["glsl", "wgsl"])
+def test_gpu_pixel_expressions_match_oracle(game, oracle, semantics):
+    cin = game.compile(PIX).cinematics[0]
+    w, h = 160, 90
+    rows = cin.uniform_rows([k / 20 for k in range(4)], w, h, audio={"bass": 0.7}, user={"knob": 1.5})
+    r = cin.renderer(w, h, semantics=semantics, animate=True)
+    got = r.render(rows)
+    r.close()
+    want = oracle.render_sequence(cin.blob, w, h, rows, True, semantics=semantics, animate=True)
+    assert np.array_equal(got, want)
+    r = cin.renderer(w, h, semantics=semantics)
+    got = r.render(rows)
+    r.close()
+    assert np.array_equal(got, oracle.render_sequence(cin.blob, w, h, rows, True, semantics=semantics))
