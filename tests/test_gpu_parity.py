@@ -449,3 +449,16 @@ def test_fbm_table_range_test_edges(game, oracle):
     want = oracle.render_sequence(cin.blob, w, h, rows, False)
     for k in range(len(cases)):
         assert np.array_equal(got[k], want[k]), f"case {cases[k]}"
+
+
+@pytest.mark.parametrize("w,h", [(65536, 2), (4, 65535), (65535, 1), (1, 4097)])
+def test_extreme_frame_shapes(game, oracle, w, h):
+    """The widest and tallest frames the ABI accepts (width <= 65536, height <= 65535), with and without feedback."""
+    for src in (C2_FBM, C4_TRAILS):
+        cin = game.compile(src).cinematics[0]
+        rows = cin.uniform_rows([0.0, 0.25], w, h, audio={"bass": 0.4})
+        r = cin.renderer(w, h)
+        got = r.render(rows)
+        r.close()
+        want = oracle.render_sequence(cin.blob, w, h, rows, cin.uses_memory)
+        assert np.array_equal(got, want)
