@@ -272,6 +272,7 @@ int render_impl(game_hip_ctx* c, const float* uniforms, uint32_t nframes, uint32
         uint32_t done = 0;
         while (done < nframes) {
             uint32_t chunk = nframes - done < c->ring ? nframes - done : c->ring;
+            if (chunk > 65535u) chunk = 65535u;   // grid.z limit
             uint32_t slot0 = c->next_slot;
             rc = launch_frames(c, done, chunk, slot0, nullptr, row0, rows);
             if (rc) return rc;
