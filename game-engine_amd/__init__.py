@@ -78,6 +78,8 @@ def _load():
         "game_hip_host_alloc": (vp, [sz]),
         "game_hip_host_free": (None, [vp]),
         "game_hip_reset_memory": (c.c_int, [vp]),
+        "game_hip_set_memory": (c.c_int, [vp, vp, u32, u32]),
+        "game_hip_particles_set_time": (c.c_int, [vp, c.c_float]),
         "game_hip_sync": (c.c_int, [vp]),
         "game_hip_frame_ptr": (vp, [vp, u32]),
         "game_hip_ring_frames": (u32, [vp]),
@@ -417,6 +419,12 @@ class Renderer:
     def reset_memory(self):
         _check(lib.game_hip_reset_memory(self._h))
 
+    def set_memory(self, frame, row0=0):
+        """Restores the feedback state from an RGBA8 frame (or a band of it starting at row0): checkpoint / resume."""
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        assert frame.ndim == 3 and frame.shape[1] == self.w and frame.shape[2] == 4
+        _check(lib.game_hip_set_memory(self._h, frame.ctypes.data, row0, frame.shape[0]))
+
     def sync(self):
         _check(lib.game_hip_sync(self._h))
 
@@ -456,6 +464,9 @@ class Renderer:
         x, y = ctypes.c_void_p(), ctypes.c_void_p()
         _check(lib.game_hip_particles_positions(self._h, ctypes.byref(x), ctypes.byref(y)))
         return x.value, y.value
+
+    def particles_set_time(self, t):
+        _check(lib.game_hip_particles_set_time(self._h, float(t)))
 
     def particles_time(self):
         t = ctypes.c_float()

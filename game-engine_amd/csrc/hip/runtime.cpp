@@ -474,6 +474,30 @@ int game_hip_reset_memory(game_hip_ctx* c)
     return GAME_OK;
 }
 
+int game_hip_set_memory(game_hip_ctx* c, const uint8_t* rgba8_frame, uint32_t row0, uint32_t rows)
+{
+    if (!c || !rgba8_frame) return set_error(GAME_E_ARGUMENT, "game_hip_set_memory: null argument");
+    if (rows == 0 || (uint64_t)row0 + rows > c->h) return set_error(GAME_E_ARGUMENT, "game_hip_set_memory: band outside the image");
+    HIP_TRY(hipSetDevice(c->device));
+    // the frame goes into the slot before the next one to be written, which the next frame reads as `previous`
+    const uint32_t slot = c->last_slot >= 0 ? (uint32_t)c->last_slot : (c->next_slot + c->ring - 1u) % c->ring;
+    if (c->last_slot < 0 && rows != c->h)   // rows outside the band must read as the zero frame a fresh context has
+        HIP_TRY(hipMemsetAsync(c->frames + (size_t)slot * c->w * c->h, 0, (size_t)c->w * c->h * 4, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->frames + (size_t)slot * c->w * c->h + (size_t)row0 * c->w, rgba8_frame, (size_t)rows * c->w * 4,
+                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // the caller's buffer may go away
+    c->last_slot = (int)slot;
+    c->next_slot = (slot + 1u) % c->ring;
+    return GAME_OK;
+}
+
+int game_hip_particles_set_time(game_hip_ctx* c, float sim_time)
+{
+    if (!c) return set_error(GAME_E_ARGUMENT, "game_hip_particles_set_time: null context");
+    c->sim_time = sim_time;
+    return GAME_OK;
+}
+
 int game_hip_sync(game_hip_ctx* c)
 {
     if (!c) return set_error(GAME_E_ARGUMENT, "game_hip_sync: null context");

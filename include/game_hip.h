@@ -214,6 +214,10 @@ int game_hip_render_band(game_hip_ctx* ctx, const float* uniforms, uint32_t nfra
 void* game_hip_host_alloc(size_t bytes);
 void game_hip_host_free(void* p);
 int game_hip_reset_memory(game_hip_ctx* ctx);          /* previous-frame store := 0 */
+/* Checkpoint / resume of the feedback state (the reference keeps it in a browser texture and has no such call):
+ * loads rows [row0, row0 + rows) of an RGBA8 frame, top row first - typically the last frame (or band) a previous
+ * run returned - as the frame the next rendered frame reads as its previous one. Synchronous. */
+int game_hip_set_memory(game_hip_ctx* ctx, const uint8_t* rgba8_frame, uint32_t row0, uint32_t rows);
 int game_hip_sync(game_hip_ctx* ctx);                  /* wait for the context's stream */
 void* game_hip_frame_ptr(game_hip_ctx* ctx, uint32_t slot);   /* device pointer of a ring slot */
 uint32_t game_hip_ring_frames(const game_hip_ctx* ctx);
@@ -242,6 +246,8 @@ int game_hip_particles_step(game_hip_ctx* ctx, float dt, uint32_t steps, uint32_
 int game_hip_particles_read(game_hip_ctx* ctx, float* pos_xy_host, float* vel_xy_host);
 int game_hip_particles_positions(game_hip_ctx* ctx, float** x_dev, float** y_dev);
 int game_hip_particles_time(game_hip_ctx* ctx, float* sim_time);
+/* Resume: the simulation time a restored particle state continues from (particles_init resets it to 0). */
+int game_hip_particles_set_time(game_hip_ctx* ctx, float sim_time);
 
 /* ── diagnostics (no counterpart in the reference) ─────────────────────────────────────────
  * Element-wise evaluation of the device math / noise functions on host arrays, so that tests can

@@ -462,3 +462,49 @@ def test_extreme_frame_shapes(game, oracle, w, h):
         r.close()
         want = oracle.render_sequence(cin.blob, w, h, rows, cin.uses_memory)
         assert np.array_equal(got, want)
+
+
+def test_checkpoint_resume_of_feedback_and_particles(game, oracle):
+    """A run cut in two and resumed in a fresh context from what the first half returned equals the uncut run."""
+    cin = game.compile(C4_TRAILS).cinematics[0]
+    w, h = 96, 54
+    rows = cin.uniform_rows([k / 30 for k in range(8)], w, h, audio={"bass": 0.6})
+    r = cin.renderer(w, h)
+    whole = r.render(rows)
+    r.close()
+    r = cin.renderer(w, h)
+    first = r.render(rows[:5])
+    r.close()
+    r = cin.renderer(w, h)
+    r.set_memory(first[-1])
+    second = r.render(rows[5:])
+    # a band restored on top of an existing state replaces just those rows
+    r.set_memory(whole[3][10:20], row0=10)
+    mixed_prev = second[-1].copy()
+    mixed_prev[10:20] = whole[3][10:20]
+    nxt = r.render(rows[7:8])
+    r.close()
+    assert np.array_equal(np.concatenate([first, second]), whole)
+    assert np.array_equal(nxt[0], oracle.render(cin.blob, w, h, rows[7], prev=mixed_prev))
+
+    src = 'cinematic "t" { gravity { rule: sin(time * 40.0) / (dist + 0.2), damping: 0.99, bounds: wrap } layer s { circle() | glow() } }'
+    cin = game.compile(src).cinematics[0]
+    p0 = oracle.seed_particles(600, seed=5)
+    r = cin.renderer(16, 16)
+    r.particles_init(p0[:, :2], p0[:, 2:])
+    r.particles_step(1 / 60, 7)
+    want_pos, want_vel = r.particles_read()
+    r.close()
+    r = cin.renderer(16, 16)
+    r.particles_init(p0[:, :2], p0[:, 2:])
+    r.particles_step(1 / 60, 3)
+    pos, vel = r.particles_read()
+    t = r.particles_time()
+    r.close()
+    r = cin.renderer(16, 16)
+    r.particles_init(pos, vel)
+    r.particles_set_time(t)
+    r.particles_step(1 / 60, 4)
+    got_pos, got_vel = r.particles_read()
+    r.close()
+    assert np.array_equal(got_pos, want_pos) and np.array_equal(got_vel, want_vel)
