@@ -55,7 +55,7 @@ int usage()
             "usage: game check FILE...\n"
             "       game render FILE --hip [--size WxH] [--frames N] [--fps F] [--batch B] [--device D]\n"
             "                   [--cinematic I] [--out PREFIX|-] [--particles N --steps S]\n"
-            "                   [--png] [--semantics glsl|wgsl] [--no-arcs] [--animate] [--lens-post] [--imports] [--lib DIR]...\n"
+            "                   [--png] [--semantics glsl|wgsl] [--no-arcs] [--animate] [--lens-post] [--imports] [--lib DIR]... [--json]\n"
             "       game compare A B [--threshold T]\n"
             "       game ir FILE | game kernel FILE [--size WxH] | game builtins\n");
     return 2;
@@ -63,7 +63,7 @@ int usage()
 
 struct Args {
     std::vector<std::string> files;
-    bool hip = false, png = false, wgsl = false, arcs = true, animate = false, lens_post = false;
+    bool hip = false, png = false, wgsl = false, arcs = true, animate = false, lens_post = false, json = false;
     int threshold = 2;
     uint32_t w = 1920, h = 1080, frames = 60, batch = 16, cinematic = 0, particles = 0, steps = 1;
     double fps = 60.0;
@@ -86,6 +86,7 @@ bool parse_args(int argc, char** argv, int first, Args& a)
         else if (s == "--no-arcs") a.arcs = false;
         else if (s == "--animate") a.animate = true;
         else if (s == "--lens-post") a.lens_post = true;
+        else if (s == "--json") a.json = true;
         else if (s == "--semantics") {
             const char* v = value("--semantics");
             if (!v) return false;
@@ -397,8 +398,12 @@ int cmd_render(const Args& a)
         if (!ok || game_hip_sync(ctx) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
         double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         double px = (double)a.frames * a.w * a.h;
-        fprintf(stderr, "[game] %s: %u frames at %ux%u, %.2f ms on device (%.0f Mpixel/s), %.3f s wall (%.0f Mpixel/s)\n", game_ir_name(ir),
-                a.frames, a.w, a.h, device_ms, px / (device_ms * 1e3), wall, px / wall / 1e6);
+        if (a.json)   // one machine-readable line instead of the sentence
+            fprintf(stderr, "{\"cinematic\": \"%s\", \"frames\": %u, \"width\": %u, \"height\": %u, \"device_ms\": %.3f, \"device_mpixel_s\": %.1f, "
+                            "\"wall_s\": %.4f, \"wall_mpixel_s\": %.1f}\n", game_ir_name(ir), a.frames, a.w, a.h, device_ms, px / (device_ms * 1e3), wall, px / wall / 1e6);
+        else
+            fprintf(stderr, "[game] %s: %u frames at %ux%u, %.2f ms on device (%.0f Mpixel/s), %.3f s wall (%.0f Mpixel/s)\n", game_ir_name(ir),
+                    a.frames, a.w, a.h, device_ms, px / (device_ms * 1e3), wall, px / wall / 1e6);
         rc = 0;
     } while (false);
     if (ctx) game_hip_destroy(ctx);

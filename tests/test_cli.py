@@ -110,6 +110,9 @@ def test_render_writes_frames_equal_to_the_library(tmp_path, game):
     r = run("render", str(f), "--hip", "--size", "96x64", "--frames", "3", "--fps", "60", "--batch", "2", "--out", out)
     assert r.returncode == 0, r.stderr
     assert "3 frames at 96x64" in r.stderr
+    rj = run("render", str(f), "--hip", "--size", "96x64", "--frames", "3", "--json")
+    rec = json.loads(rj.stderr.strip().splitlines()[-1])
+    assert rec["frames"] == 3 and rec["width"] == 96 and rec["device_mpixel_s"] > 0
     cin = game.compile(C1_HELLO).cinematics[0]
     want = cin.renderer(96, 64).render(cin.uniform_rows([k / 60.0 for k in range(3)], 96, 64))
     for k in range(3):
