@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 using namespace game;
@@ -90,13 +92,15 @@ int hip_fail(const char* what, hipError_t e)
     } while (0)
 
 // Compiles HIP source for gfx950 with the device header attached. No device is needed.
+// Code objects already built in this process, keyed by options + source: contexts for the same cinematic (one per
+// GPU, or re-created per request) share one hiprtc compile. Bounded: the cache is dropped when it reaches 256 entries.
+std::mutex g_code_mu;
+std::unordered_map<std::string, std::vector<char>> g_code_cache;
+
+int compile_hip_uncached(const std::string& src, const char* name, const std::vector<std::string>& flags, std::vector<char>& code);
+
 int compile_hip(const std::string& src, const char* name, std::vector<char>& code)
 {
-    hiprtcProgram prog;
-    const char* hdr_src[] = {kDeviceHeader};
-    const char* hdr_name[] = {"game_device.h"};
-    hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), name, 1, hdr_src, hdr_name);
-    if (r != HIPRTC_SUCCESS) return set_error(GAME_E_HIP, std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r));
     // One rounding per source operator: contraction off; fma only where the source says fma.
     // No SLP vectorisation: packed FP32 (v_pk_*_f32) issues at half rate on gfx950, so pairing two
     // scalar operations into one packed instruction only adds the moves that build the pairs.
@@ -112,6 +116,30 @@ int compile_hip(const std::string& src, const char* name, std::vector<char>& cod
             i = j + 1;
         }
     }
+    std::string key;
+    for (const std::string& f : flags) { key += f; key += '\n'; }
+    key += '\0';
+    key += src;
+    {
+        std::lock_guard<std::mutex> lock(g_code_mu);
+        auto it = g_code_cache.find(key);
+        if (it != g_code_cache.end()) { code = it->second; return GAME_OK; }
+    }
+    int rc = compile_hip_uncached(src, name, flags, code);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(g_code_mu);
+    if (g_code_cache.size() >= 256) g_code_cache.clear();
+    g_code_cache.emplace(std::move(key), code);
+    return GAME_OK;
+}
+
+int compile_hip_uncached(const std::string& src, const char* name, const std::vector<std::string>& flags, std::vector<char>& code)
+{
+    hiprtcProgram prog;
+    const char* hdr_src[] = {kDeviceHeader};
+    const char* hdr_name[] = {"game_device.h"};
+    hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), name, 1, hdr_src, hdr_name);
+    if (r != HIPRTC_SUCCESS) return set_error(GAME_E_HIP, std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r));
     std::vector<const char*> opts;
     for (const std::string& f : flags) opts.push_back(f.c_str());
     r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
