@@ -81,6 +81,8 @@ def _load():
         "game_hip_set_memory": (c.c_int, [vp, vp, u32, u32]),
         "game_hip_particles_set_time": (c.c_int, [vp, c.c_float]),
         "game_hip_sync": (c.c_int, [vp]),
+        "game_hip_timing_begin": (c.c_int, [vp]),
+        "game_hip_timing_end": (c.c_int, [vp, c.POINTER(c.c_float), c.POINTER(u32)]),
         "game_hip_frame_ptr": (vp, [vp, u32]),
         "game_hip_ring_frames": (u32, [vp]),
         "game_hip_last_kernel_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(u32)]),
@@ -427,6 +429,16 @@ class Renderer:
 
     def sync(self):
         _check(lib.game_hip_sync(self._h))
+
+    def timing_begin(self):
+        """Calls until timing_end() each record their own event pair; nothing waits in between."""
+        _check(lib.game_hip_timing_begin(self._h))
+
+    def timing_end(self):
+        """(summed device ms, launches) of the calls since timing_begin(); waits for them."""
+        ms, n = ctypes.c_float(), ctypes.c_uint32()
+        _check(lib.game_hip_timing_end(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
 
     def last_kernel_ms(self):
         ms, n = ctypes.c_float(), ctypes.c_uint32()

@@ -43,7 +43,14 @@ struct game_hip_ctx {
     const float* vlut = nullptr;  // voronoi feature-point table of this device (shared, not owned)
     const float* slut = nullptr;  // simplex corner table of this device (shared, not owned)
     std::vector<float> utab_host;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;     // events around the launches of the latest call
+    // game_hip_timing_begin/_end: every call in between gets an event pair of its own, so the caller can queue
+    // many calls without waiting and read the summed device time afterwards
+    struct TimedCall { hipEvent_t e0, e1; uint32_t launches; };
+    hipEvent_t ev_own0 = nullptr, ev_own1 = nullptr;   // the pair used outside a timing section
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<TimedCall> ev_pending;
+    bool timing = false;
     float last_ms = 0.0f;
     uint32_t last_launches = 0;
     // particles
@@ -270,6 +277,26 @@ int launch_frames(game_hip_ctx* c, uint32_t frame0, uint32_t count, uint32_t slo
     return GAME_OK;
 }
 
+// Picks the event pair for the call that is starting.
+int begin_call_events(game_hip_ctx* c)
+{
+    if (!c->timing) { c->ev0 = c->ev_own0; c->ev1 = c->ev_own1; return GAME_OK; }
+    if (c->ev_pool.empty()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIP_TRY(hipEventCreate(&a));
+        hipError_t e = hipEventCreate(&b);
+        if (e != hipSuccess) { (void)hipEventDestroy(a); return hip_fail("hipEventCreate", e); }
+        c->ev_pool.emplace_back(a, b);
+    }
+    c->ev0 = c->ev_pool.back().first; c->ev1 = c->ev_pool.back().second;
+    c->ev_pool.pop_back();
+    return GAME_OK;
+}
+void end_call_events(game_hip_ctx* c)
+{
+    if (c->timing) c->ev_pending.push_back({c->ev0, c->ev1, c->last_launches});
+}
+
 int render_impl(game_hip_ctx* c, const float* uniforms, uint32_t nframes, uint32_t row0, uint32_t rows, uint8_t* host)
 {
     if (!c || !uniforms) return set_error(GAME_E_ARGUMENT, "game_hip_render: null argument");
@@ -281,6 +308,8 @@ int render_impl(game_hip_ctx* c, const float* uniforms, uint32_t nframes, uint32
     const size_t frame_px = (size_t)c->w * c->h;
     const size_t band_bytes = (size_t)rows * c->w * 4;
     c->last_launches = 0;
+    rc = begin_call_events(c);
+    if (rc) return rc;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (c->ir.uses_memory) {
         // frame-serial: frame k reads the slot frame k-1 was written to
@@ -318,6 +347,7 @@ int render_impl(game_hip_ctx* c, const float* uniforms, uint32_t nframes, uint32
         }
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    end_call_events(c);
     if (host) HIP_TRY(hipStreamSynchronize(c->stream));
     return GAME_OK;
 }
@@ -416,8 +446,9 @@ int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int d
     if ((e = hipModuleLoadData(&c->mod, code.data())) != hipSuccess) return fail("hipModuleLoadData", e);
     if ((e = hipModuleGetFunction(&c->fn, c->mod, "game_frame")) != hipSuccess) return fail("hipModuleGetFunction", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
-    if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return fail("hipEventCreate", e);
-    if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev_own0)) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev_own1)) != hipSuccess) return fail("hipEventCreate", e);
+    c->ev0 = c->ev_own0; c->ev1 = c->ev_own1;
     rc = ensure_ring(c, c->ir.uses_memory ? 2u : 4u);
     if (rc) { game_hip_destroy(c); return rc; }
     if (uses_lattice_noise(c->ir) && !getenv("GAME_HIP_NO_LUT")) {   // the variable is a tuning hook
@@ -463,8 +494,10 @@ void game_hip_destroy(game_hip_ctx* c)
     }
     if (c->vx) (void)hipFree(c->vx);
     if (c->vy) (void)hipFree(c->vy);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_own0) (void)hipEventDestroy(c->ev_own0);
+    if (c->ev_own1) (void)hipEventDestroy(c->ev_own1);
+    for (auto& p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto& t : c->ev_pending) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
     if (c->mod) (void)hipModuleUnload(c->mod);
     if (c->gmod) (void)hipModuleUnload(c->gmod);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -548,6 +581,39 @@ int game_hip_last_kernel_ms(game_hip_ctx* c, float* ms, uint32_t* launches)
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
     if (launches) *launches = c->last_launches;
+    return GAME_OK;
+}
+
+int game_hip_timing_begin(game_hip_ctx* c)
+{
+    if (!c) return set_error(GAME_E_ARGUMENT, "game_hip_timing_begin: null context");
+    if (c->timing) return set_error(GAME_E_ARGUMENT, "game_hip_timing_begin: a timing section is already open");
+    c->timing = true;
+    return GAME_OK;
+}
+
+int game_hip_timing_end(game_hip_ctx* c, float* total_ms, uint32_t* launches)
+{
+    if (!c || !total_ms) return set_error(GAME_E_ARGUMENT, "game_hip_timing_end: null argument");
+    if (!c->timing) return set_error(GAME_E_ARGUMENT, "game_hip_timing_end: no timing section is open");
+    HIP_TRY(hipSetDevice(c->device));
+    c->timing = false;
+    c->ev0 = c->ev_own0; c->ev1 = c->ev_own1;
+    double sum = 0.0;
+    uint32_t n = 0;
+    hipError_t err = hipSuccess;
+    for (auto& t : c->ev_pending) {
+        float ms = 0.0f;
+        if (err == hipSuccess) err = hipEventSynchronize(t.e1);
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, t.e0, t.e1);
+        sum += ms;
+        n += t.launches;
+        c->ev_pool.emplace_back(t.e0, t.e1);
+    }
+    c->ev_pending.clear();
+    if (err != hipSuccess) return hip_fail("game_hip_timing_end", err);
+    *total_ms = (float)sum;
+    if (launches) *launches = n;
     return GAME_OK;
 }
 
@@ -640,6 +706,7 @@ int game_hip_particles_step(game_hip_ctx* c, float dt, uint32_t steps, uint32_t 
         return set_error(GAME_E_ARGUMENT, "game_hip_particles_step: a partial range advances one step per call (exchange positions between steps)");
     HIP_TRY(hipSetDevice(c->device));
     c->last_launches = 0;
+    { int erc = begin_call_events(c); if (erc) return erc; }
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     for (uint32_t s = 0; s < steps; ++s) {
         c->sim_time = c->sim_time + dt;   // `_time += dt` before the dispatch (gravity.rs:158)
@@ -655,6 +722,7 @@ int game_hip_particles_step(game_hip_ctx* c, float dt, uint32_t steps, uint32_t 
         c->cur = 1 - c->cur;
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    end_call_events(c);
     return GAME_OK;
 }
 

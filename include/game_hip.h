@@ -224,6 +224,12 @@ uint32_t game_hip_ring_frames(const game_hip_ctx* ctx);
 /* Device time of the kernels of the last render call, from HIP events recorded on the context's
  * stream around the launches (milliseconds), and the number of launches it covers. */
 int game_hip_last_kernel_ms(game_hip_ctx* ctx, float* ms, uint32_t* launches);
+/* The same over many calls without waiting in between: every render / particle-step call between _begin and
+ * _end records an event pair of its own on the render stream; _end waits for the last of them and returns the
+ * summed device time and the number of kernel launches. (game_hip_last_kernel_ms after a call inside the section
+ * still works and waits for that call.) */
+int game_hip_timing_begin(game_hip_ctx* ctx);
+int game_hip_timing_end(game_hip_ctx* ctx, float* total_ms, uint32_t* launches);
 /* Source text of the generated kernel (for inspection and tests). */
 const char* game_hip_kernel_source(const game_hip_ctx* ctx);
 /* Compile the generated kernel for gfx950 without touching a device (build-time check). */

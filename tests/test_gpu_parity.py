@@ -508,3 +508,22 @@ def test_checkpoint_resume_of_feedback_and_particles(game, oracle):
     got_pos, got_vel = r.particles_read()
     r.close()
     assert np.array_equal(got_pos, want_pos) and np.array_equal(got_vel, want_vel)
+
+
+def test_timing_section_sums_queued_calls(game):
+    cin = game.compile(C2_FBM).cinematics[0]
+    r = cin.renderer(320, 180)
+    r.set_ring(4)
+    rows = cin.uniform_rows([0.0, 0.1, 0.2, 0.3], 320, 180)
+    r.render(rows, readback=False)
+    one, n1 = r.last_kernel_ms()
+    r.timing_begin()
+    for _ in range(5):
+        r.render(rows, readback=False)
+    total, n = r.timing_end()
+    assert n == 5 * n1 and total > 0 and 2.0 * one < total < 20.0 * one + 1.0
+    with pytest.raises(game.GameError):
+        r.timing_end()
+    r.render(rows, readback=False)           # outside a section the single-call query still works
+    assert r.last_kernel_ms()[1] == n1
+    r.close()
