@@ -313,8 +313,10 @@ void Animator::step(double time_s, double dt, float* row, uint32_t what, const c
                     break;
                 }
                 default:                       // Range: Math.min(Math.max(v, lo), hi)
-                    v = v > op.lo ? v : op.lo;
-                    v = v < op.hi ? v : op.hi;
+                    if (v == v) {              // Math.max / Math.min keep a NaN
+                        v = v > op.lo ? v : op.lo;
+                        v = v < op.hi ? v : op.hi;
+                    }
                     break;
                 }
             }
