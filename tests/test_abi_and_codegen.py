@@ -96,3 +96,38 @@ def test_wgsl_semantics_kernels_compile_and_call_the_variants(game):
     for name in ("noise_mix", "voronoi", "simplex"):
         if name in GALLERY:
             assert game.compile(GALLERY[name]).cinematics[0].compile_only(semantics="wgsl") > 0
+
+
+def test_header_is_plain_c_and_a_c_consumer_links(tmp_path):
+    """The boundary is a C ABI: the header compiles as C11 with -pedantic and a C program drives the front end."""
+    import subprocess
+    src = tmp_path / "consumer.c"
+    src.write_text(r'''
+#include "game_hip.h"
+#include <stdio.h>
+#include <string.h>
+int main(void) {
+    const char* text = "cinematic \"c\" { layer a { fn: circle(0.3) | glow(2.0) | tint(1.0, 0.5, 0.2) } }";
+    game_program* prog = 0;
+    if (game_front_compile(text, strlen(text), &prog) != 0) { printf("compile failed: %s\n", game_last_error()); return 1; }
+    const game_ir* ir = game_program_ir(prog, 0);
+    float row[16];
+    game_ir_default_uniforms(ir, 0.5f, 64, 36, row);
+    printf("%s %u %d %.1f %.1f\n", game_ir_name(ir), game_ir_frame_floats(ir), game_ir_uses_memory(ir), row[6], row[7]);
+    const char* bad = "cinematic \"c\" { layer a { fn: circle(0.3) | blorp(1.0) } }";
+    game_program* p2 = 0;
+    int rc = game_front_compile(bad, strlen(bad), &p2);
+    printf("rc=%d %s\n", rc, game_last_error());
+    game_program_free(prog);
+    return 0;
+}
+''')
+    pkg = os.path.join(ROOT, "game-engine_amd")
+    exe = tmp_path / "consumer"
+    subprocess.check_call(["gcc", "-std=c11", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", pkg, "-lgame_hip", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == "c 10 0 64.0 36.0"
+    assert lines[1].startswith("rc=1 ") and "unknown stage function: 'blorp'" in lines[1]
