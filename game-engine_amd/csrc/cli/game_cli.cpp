@@ -33,6 +33,7 @@
 #include <fstream>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/game_hip.h"
@@ -55,7 +56,7 @@ int usage()
             "usage: game check FILE...\n"
             "       game render FILE --hip [--size WxH] [--frames N] [--fps F] [--batch B] [--device D]\n"
             "                   [--cinematic I] [--out PREFIX|-] [--particles N --steps S]\n"
-            "                   [--png] [--semantics glsl|wgsl] [--no-arcs] [--animate] [--lens-post] [--imports] [--lib DIR]... [--json]\n"
+            "                   [--png] [--semantics glsl|wgsl] [--no-arcs] [--animate] [--lens-post] [--imports] [--lib DIR]... [--json] [--gpus N]\n"
             "       game compare A B [--threshold T]\n"
             "       game ir FILE | game kernel FILE [--size WxH] | game builtins\n");
     return 2;
@@ -65,7 +66,7 @@ struct Args {
     std::vector<std::string> files;
     bool hip = false, png = false, wgsl = false, arcs = true, animate = false, lens_post = false, json = false;
     int threshold = 2;
-    uint32_t w = 1920, h = 1080, frames = 60, batch = 16, cinematic = 0, particles = 0, steps = 1;
+    uint32_t w = 1920, h = 1080, frames = 60, batch = 16, cinematic = 0, particles = 0, steps = 1, gpus = 1;
     double fps = 60.0;
     int device = 0;
     std::string out;
@@ -102,6 +103,7 @@ bool parse_args(int argc, char** argv, int first, Args& a)
         else if (s == "--batch") { const char* v = value("--batch"); if (!v) return false; a.batch = (uint32_t)strtoul(v, nullptr, 10); }
         else if (s == "--imports") a.imports = true;
         else if (s == "--lib") { const char* v = value("--lib"); if (!v) return false; a.lib_dirs.push_back(v); a.imports = true; }
+        else if (s == "--gpus") { const char* v = value("--gpus"); if (!v) return false; a.gpus = (uint32_t)strtoul(v, nullptr, 10); if (a.gpus < 1 || a.gpus > 64) { fprintf(stderr, "game: --gpus wants 1..64\n"); return false; } }
         else if (s == "--device") { const char* v = value("--device"); if (!v) return false; a.device = atoi(v); }
         else if (s == "--cinematic") { const char* v = value("--cinematic"); if (!v) return false; a.cinematic = (uint32_t)strtoul(v, nullptr, 10); }
         else if (s == "--particles") { const char* v = value("--particles"); if (!v) return false; a.particles = (uint32_t)strtoul(v, nullptr, 10); }
@@ -318,6 +320,71 @@ int cmd_compare(const Args& a)
     return max_abs == 0 ? 0 : 1;
 }
 
+// Renders frames first, first + stride, ... of the cinematic on one GPU context (one thread per context when
+// --gpus N splits a stateless cinematic frame k -> GPU k mod N). The animator is stepped through every frame
+// index so that its temporal operators see the whole sequence whichever frames this worker renders.
+bool render_frames(const game_ir* ir, const Args& a, game_hip_ctx* ctx, uint32_t first, uint32_t stride, double& device_ms, std::string& error)
+{
+    auto fail = [&](const std::string& m) { error = m; return false; };
+    const uint32_t batch = a.batch ? a.batch : 1;
+    if (game_hip_set_ring(ctx, game_ir_uses_memory(ir) ? 2u : batch) != GAME_OK) return fail(game_last_error());
+    const uint32_t nf = game_ir_frame_floats(ir);
+    std::vector<float> rows((size_t)batch * nf);
+    std::vector<uint32_t> index(batch);
+    // frames come back into page-locked memory (DMA at PCIe rate)
+    struct Pinned {
+        uint8_t* p = nullptr;
+        ~Pinned() { game_hip_host_free(p); }
+        bool empty() const { return p == nullptr; }
+        uint8_t* data() const { return p; }
+    } host;
+    if (!a.out.empty()) {
+        host.p = (uint8_t*)game_hip_host_alloc((size_t)batch * a.w * a.h * 4);
+        if (!host.p) return fail(game_last_error());
+    }
+    // --animate: modulation, temporal operators and resonance of the parameters run on the host, frame by frame
+    struct Anim {
+        game_animator* p = nullptr;
+        ~Anim() { game_animator_destroy(p); }
+    } anim;
+    if (a.animate && game_animator_create(ir, a.fps, &anim.p) != GAME_OK) return fail(game_last_error());
+    std::vector<float> scratch(nf);
+    uint32_t n = 0;
+    auto flush = [&]() -> bool {
+        if (n == 0) return true;
+        if (game_hip_render(ctx, rows.data(), n, host.empty() ? nullptr : host.data()) != GAME_OK) return fail(game_last_error());
+        float ms = 0; uint32_t launches = 0;
+        game_hip_last_kernel_ms(ctx, &ms, &launches);
+        device_ms += ms;
+        for (uint32_t k = 0; k < n && !host.empty(); ++k) {
+            const uint8_t* frame = host.data() + (size_t)k * a.w * a.h * 4;
+            if (a.out == "-") {   // raw RGBA8 frames, top row first, back to back: pipe into an encoder
+                if (fwrite(frame, 1, (size_t)a.w * a.h * 4, stdout) != (size_t)a.w * a.h * 4) return fail("short write to stdout");
+                continue;
+            }
+            char name[32];
+            snprintf(name, sizeof name, a.png ? "_%05u.png" : "_%05u.ppm", index[k]);
+            if (!(a.png ? write_png(a.out + name, frame, a.w, a.h) : write_ppm(a.out + name, frame, a.w, a.h))) return fail("cannot write " + a.out + name);
+        }
+        n = 0;
+        return true;
+    };
+    for (uint32_t f = 0; f < a.frames; ++f) {
+        const bool mine = f >= first && (f - first) % stride == 0;
+        if (!mine && !anim.p) continue;
+        float* row = mine ? rows.data() + (size_t)n * nf : scratch.data();
+        game_ir_default_uniforms(ir, (float)(f / a.fps), a.w, a.h, row);
+        if (anim.p) game_animator_step(anim.p, f / a.fps, 1.0 / a.fps, row, (a.arcs ? 1u : 0u) | 6u, nullptr, nullptr, 0);
+        else if (a.arcs) game_ir_arc_update(ir, f / a.fps, row);   // the cinematic's own timeline animates its parameters
+        if (!mine) continue;
+        index[n++] = f;
+        if (n == batch && !flush()) return false;
+    }
+    if (!flush()) return false;
+    if (game_hip_sync(ctx) != GAME_OK) return fail(game_last_error());
+    return true;
+}
+
 int cmd_render(const Args& a)
 {
     if (a.files.size() != 1) return usage();
@@ -343,59 +410,43 @@ int cmd_render(const Args& a)
             rc = 0;
             break;
         }
-        const uint32_t batch = a.batch ? a.batch : 1;
-        if (game_hip_set_ring(ctx, game_ir_uses_memory(ir) ? 2u : batch) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
-        const uint32_t nf = game_ir_frame_floats(ir);
-        std::vector<float> rows((size_t)batch * nf);
-        // frames come back into page-locked memory (DMA at PCIe rate)
-        struct Pinned {
-            uint8_t* p = nullptr;
-            ~Pinned() { game_hip_host_free(p); }
-            bool empty() const { return p == nullptr; }
-            uint8_t* data() const { return p; }
-        } host;
-        if (!a.out.empty()) {
-            host.p = (uint8_t*)game_hip_host_alloc((size_t)batch * a.w * a.h * 4);
-            if (!host.p) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
-        }
-        // --animate: modulation, temporal operators and resonance of the parameters run on the host, frame by frame
-        struct Anim {
-            game_animator* p = nullptr;
-            ~Anim() { game_animator_destroy(p); }
-        } anim;
-        if (a.animate && game_animator_create(ir, a.fps, &anim.p) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
+        const uint32_t flags = (a.wgsl ? (uint32_t)GAME_HIP_SEMANTICS_WGSL : 0u) | (a.animate ? (uint32_t)GAME_HIP_ANIMATE_ARGS : 0u) | (a.lens_post ? (uint32_t)GAME_HIP_LENS_POST : 0u);
         auto t0 = std::chrono::steady_clock::now();
         double device_ms = 0;
-        bool ok = true;
-        for (uint32_t done = 0; done < a.frames && ok; done += batch) {
-            uint32_t n = a.frames - done < batch ? a.frames - done : batch;
-            for (uint32_t k = 0; k < n; ++k) {
-                float* row = rows.data() + (size_t)k * nf;
-                game_ir_default_uniforms(ir, (float)((done + k) / a.fps), a.w, a.h, row);
-                if (anim.p) game_animator_step(anim.p, (done + k) / a.fps, 1.0 / a.fps, row, (a.arcs ? 1u : 0u) | 6u, nullptr, nullptr, 0);
-                else if (a.arcs) game_ir_arc_update(ir, (done + k) / a.fps, row);   // the cinematic's own timeline animates its parameters
+        if (a.gpus <= 1) {
+            std::string error;
+            if (!render_frames(ir, a, ctx, 0, 1, device_ms, error)) { fprintf(stderr, "game render: %s\n", error.c_str()); break; }
+        } else {
+            // one context and one host thread per GPU, frame k -> GPU k mod N, no exchange between them
+            if (game_ir_uses_memory(ir)) { fprintf(stderr, "game render: --gpus splits whole frames; a memory cinematic is frame-serial (shard it by bands, one process per GPU)\n"); break; }
+            if (a.out == "-") { fprintf(stderr, "game render: --out - keeps frame order and needs --gpus 1\n"); break; }
+            int ndev = 0;
+            if (game_hip_device_count(&ndev) != GAME_OK || ndev < 1) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
+            const bool share = getenv("GAME_CLI_SHARE_DEVICE") != nullptr;   // test hook: every worker on --device
+            if (!share && a.device + (int)a.gpus > ndev) { fprintf(stderr, "game render: --gpus %u from device %d needs %d devices, %d visible\n", a.gpus, a.device, a.device + (int)a.gpus, ndev); break; }
+            std::vector<game_hip_ctx*> ctxs(a.gpus, nullptr);
+            std::vector<std::string> errors(a.gpus);
+            std::vector<double> ms(a.gpus, 0.0);
+            std::vector<char> good(a.gpus, 0);
+            ctxs[0] = ctx;
+            bool created = true;
+            for (uint32_t g = 1; g < a.gpus && created; ++g)
+                if (game_hip_create_ex(ir, a.w, a.h, share ? a.device : a.device + (int)g, flags, &ctxs[g]) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); created = false; }
+            if (created) {
+                std::vector<std::thread> workers;
+                for (uint32_t g = 0; g < a.gpus; ++g)
+                    workers.emplace_back([&, g]() { good[g] = render_frames(ir, a, ctxs[g], g, a.gpus, ms[g], errors[g]) ? 1 : 0; });
+                for (std::thread& t : workers) t.join();
             }
-            if (game_hip_render(ctx, rows.data(), n, host.empty() ? nullptr : host.data()) != GAME_OK) { ok = false; break; }
-            float ms = 0; uint32_t launches = 0;
-            game_hip_last_kernel_ms(ctx, &ms, &launches);
-            device_ms += ms;
-            for (uint32_t k = 0; k < n && !host.empty(); ++k) {
-                const uint8_t* frame = host.data() + (size_t)k * a.w * a.h * 4;
-                if (a.out == "-") {   // raw RGBA8 frames, top row first, back to back: pipe into an encoder
-                    if (fwrite(frame, 1, (size_t)a.w * a.h * 4, stdout) != (size_t)a.w * a.h * 4) { fprintf(stderr, "game render: short write to stdout\n"); ok = false; break; }
-                    continue;
-                }
-                char name[32];
-                snprintf(name, sizeof name, a.png ? "_%05u.png" : "_%05u.ppm", done + k);
-                if (!(a.png ? write_png(a.out + name, frame, a.w, a.h) : write_ppm(a.out + name, frame, a.w, a.h))) {
-                    fprintf(stderr, "game render: cannot write %s%s\n", a.out.c_str(), name);
-                    ok = false;
-                    break;
-                }
+            bool all = created;
+            for (uint32_t g = 0; g < a.gpus; ++g) {
+                if (created && !good[g]) { fprintf(stderr, "game render: GPU worker %u: %s\n", g, errors[g].c_str()); all = false; }
+                if (ms[g] > device_ms) device_ms = ms[g];   // the workers run side by side: the slowest one is the device time
+                if (g > 0 && ctxs[g]) game_hip_destroy(ctxs[g]);
             }
+            if (!all) break;
         }
         if (a.out == "-") fflush(stdout);
-        if (!ok || game_hip_sync(ctx) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
         double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         double px = (double)a.frames * a.w * a.h;
         if (a.json)   // one machine-readable line instead of the sentence

@@ -186,3 +186,30 @@ def test_render_with_imports_and_lens_post(tmp_path, game):
     data = open(out + "_00000.ppm", "rb").read()
     header = b"P6\n64 36\n255\n"
     assert np.array_equal(np.frombuffer(data[len(header):], dtype=np.uint8).reshape(36, 64, 3), want[0][..., :3])
+
+
+@pytest.mark.gpu
+def test_render_split_over_gpu_workers_writes_the_same_frames(tmp_path, game):
+    """--gpus N: one context and one host thread per GPU, frame k -> worker k mod N. With one GPU on the box the workers
+    share it (test hook); the files must equal the single-worker run's, animated parameters included."""
+    src = '''cinematic "pulse" {
+      layer orb { fn: rotate(time * 2.0) | star(5.0, radius, 0.1) | glow(2.0) | tint(1.0, 0.7, 0.3)
+        radius: 0.25 ~ sin(time * 6.0) * 0.1 <> 100ms }
+    }'''
+    f = tmp_path / "p.game"
+    f.write_text(src)
+    one, three = str(tmp_path / "one"), str(tmp_path / "three")
+    common = ["render", str(f), "--hip", "--animate", "--size", "96x64", "--frames", "7", "--fps", "30", "--batch", "2"]
+    r = run(*common, "--out", one)
+    assert r.returncode == 0, r.stderr
+    r = run(*common, "--gpus", "3", "--out", three, env={**os.environ, "GAME_CLI_SHARE_DEVICE": "1"})
+    assert r.returncode == 0, r.stderr
+    for k in range(7):
+        assert open(f"{one}_{k:05d}.ppm", "rb").read() == open(f"{three}_{k:05d}.ppm", "rb").read(), k
+    # more workers than devices is refused without the hook; memory cinematics are refused outright
+    r = run(*common, "--gpus", "64", "--out", three)
+    assert r.returncode == 1 and "devices" in r.stderr
+    m = tmp_path / "m.game"
+    m.write_text(C4_TRAILS)
+    r = run("render", str(m), "--hip", "--size", "64x36", "--frames", "2", "--gpus", "2", env={**os.environ, "GAME_CLI_SHARE_DEVICE": "1"})
+    assert r.returncode == 1 and "frame-serial" in r.stderr
