@@ -638,6 +638,7 @@ static int alloc_particles(game_hip_ctx* c, uint32_t n)
 {
     if (c->n == n && c->px[0]) return GAME_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n = 0;   // stays 0 if an allocation below fails, so a later call starts over
     for (int i = 0; i < 2; ++i) {
         if (c->px[i]) HIP_TRY(hipFree(c->px[i]));
         if (c->py[i]) HIP_TRY(hipFree(c->py[i]));
