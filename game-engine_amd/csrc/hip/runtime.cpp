@@ -221,7 +221,7 @@ float host_fract(float x)
 int ensure_ring(game_hip_ctx* c, uint32_t ring)
 {
     if (c->frames && c->ring == ring) return GAME_OK;
-    if (c->frames) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->frames)); c->frames = nullptr; }
+    if (c->frames) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->frames)); c->frames = nullptr; c->ring = 0; }
     size_t bytes = (size_t)ring * c->w * c->h * 4;
     HIP_TRY(hipMalloc((void**)&c->frames, bytes));
     HIP_TRY(hipMemsetAsync(c->frames, 0, bytes, c->stream));
@@ -302,6 +302,7 @@ int render_impl(game_hip_ctx* c, const float* uniforms, uint32_t nframes, uint32
     if (!c || !uniforms) return set_error(GAME_E_ARGUMENT, "game_hip_render: null argument");
     if (rows == 0 || (uint64_t)row0 + rows > c->h) return set_error(GAME_E_ARGUMENT, "game_hip_render: band outside the image");
     if (nframes == 0) return GAME_OK;
+    if (!c->frames || c->ring == 0) return set_error(GAME_E_HIP, "game_hip_render: the frame ring is not allocated (an earlier game_hip_set_ring failed)");
     HIP_TRY(hipSetDevice(c->device));
     int rc = upload_rows(c, uniforms, nframes);
     if (rc) return rc;
@@ -539,6 +540,7 @@ int game_hip_set_memory(game_hip_ctx* c, const uint8_t* rgba8_frame, uint32_t ro
 {
     if (!c || !rgba8_frame) return set_error(GAME_E_ARGUMENT, "game_hip_set_memory: null argument");
     if (rows == 0 || (uint64_t)row0 + rows > c->h) return set_error(GAME_E_ARGUMENT, "game_hip_set_memory: band outside the image");
+    if (!c->frames || c->ring == 0) return set_error(GAME_E_HIP, "game_hip_set_memory: the frame ring is not allocated");
     HIP_TRY(hipSetDevice(c->device));
     // the frame goes into the slot before the next one to be written, which the next frame reads as `previous`
     const uint32_t slot = c->last_slot >= 0 ? (uint32_t)c->last_slot : (c->next_slot + c->ring - 1u) % c->ring;
