@@ -244,7 +244,7 @@ int upload_rows(game_hip_ctx* c, const float* uniforms, uint32_t nframes)
         if (c->shape.animate) eval_derived(c->ir, src, dst + c->shape.derived_slot);
     }
     if (need > c->utab_cap) {
-        if (c->utab_dev) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->utab_dev)); c->utab_dev = nullptr; }
+        if (c->utab_dev) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->utab_dev)); c->utab_dev = nullptr; c->utab_cap = 0; }
         size_t cap = need < 4096 ? 4096 : need;
         HIP_TRY(hipMalloc((void**)&c->utab_dev, cap * 4));
         c->utab_cap = cap;
