@@ -195,17 +195,18 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
          "    const float* vlut;\n"
          "    const float* slut;\n"
          "};\n\n";
-    k += "extern \"C\" __global__ __launch_bounds__(256) void game_frame(GameFrameParams P)\n{\n";
+    const std::string wg = std::to_string(shape.wg);
+    k += "extern \"C\" __global__ __launch_bounds__(" + wg + ") void game_frame(GameFrameParams P)\n{\n";
     // A lane owns pixels_per_lane consecutive pixels of one row, a wave 64 * pixels_per_lane of them,
     // a 256-thread workgroup four such strips side by side: every store instruction of a wave writes
     // one contiguous run of the row (256 B, or 1 KiB as 16-byte stores when pixels_per_lane is 4).
-    // Shapes with 8 or 16 pixels per lane give a lane two or four such 16-byte vectors 1024 pixels apart (every
+    // Shapes with 8 or 16 pixels per lane give a lane two or four such 16-byte vectors one workgroup strip (4 x workgroup size pixels) apart (every
     // load and store instruction of a wave still covers one contiguous KiB) and issue all previous-frame loads
     // before any arithmetic: more bytes in flight per wave for the cinematics the memory system bounds.
     const uint32_t nvec = shape.pixels_per_lane >= 4 ? shape.pixels_per_lane / 4u : 0u;
     const std::string ppl = std::to_string(shape.pixels_per_lane);
-    if (nvec > 1) k += "    const gd_u32 x0 = blockIdx.x * " + std::to_string(256u * shape.pixels_per_lane) + "u + threadIdx.x * 4u;\n";
-    else k += "    const gd_u32 x0 = (blockIdx.x * 256u + threadIdx.x) * " + ppl + "u;\n";
+    if (nvec > 1) k += "    const gd_u32 x0 = blockIdx.x * " + std::to_string(shape.wg * shape.pixels_per_lane) + "u + threadIdx.x * 4u;\n";
+    else k += "    const gd_u32 x0 = (blockIdx.x * " + wg + "u + threadIdx.x) * " + ppl + "u;\n";
     k += "    const gd_u32 ty = P.row0 + blockIdx.y;\n";
     k += "    if (x0 >= P.w) return;\n";
     k += "    const gd_u32 fidx = blockIdx.z;\n";
@@ -227,11 +228,11 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
             k += "    gd_u32x4 pv[" + nv + "];\n";
             k += "#pragma unroll\n    for (gd_u32 v = 0; v < " + nv + "u; ++v) {\n"
                  "        pv[v] = gd_u32x4{0u, 0u, 0u, 0u};\n"
-                 "        if (P.prev && x0 + v * 1024u < P.w) pv[v] = *(const gd_u32x4*)(P.prev + (unsigned long long)ty * P.w + x0 + v * 1024u);\n"
+                 "        if (P.prev && x0 + v * " + std::to_string(shape.wg * 4u) + "u < P.w) pv[v] = *(const gd_u32x4*)(P.prev + (unsigned long long)ty * P.w + x0 + v * " + std::to_string(shape.wg * 4u) + "u);\n"
                  "    }\n";
         }
         k += "#pragma unroll\n    for (gd_u32 v = 0; v < " + nv + "u; ++v) {\n";
-        k += "    const gd_u32 xv = x0 + v * 1024u;\n";
+        k += "    const gd_u32 xv = x0 + v * " + std::to_string(shape.wg * 4u) + "u;\n";
         k += "    if (xv >= P.w) break;\n";
         k += "    gd_u32x4 q;\n";
         k += "#pragma unroll\n    for (gd_u32 kx = 0; kx < 4u; ++kx) {\n    const gd_u32 x = xv + kx;\n";

@@ -201,6 +201,10 @@ KernelShape shape_for(const Ir& ir, uint32_t width, uint32_t flags = 0)
         int v = atoi(e);
         if (v == 1 || ((v == 4 || v == 8 || v == 16) && width % 4u == 0u)) s.pixels_per_lane = (uint32_t)v;
     }
+    if (const char* e = getenv("GAME_HIP_WG")) {    // tuning hook
+        int v = atoi(e);
+        if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) s.wg = (uint32_t)v;
+    }
     uint32_t row = BU_COUNT + (uint32_t)ir.uniforms.size();
     s.time_slot = row;
     s.aspect_slot = row + 1;
@@ -271,9 +275,9 @@ int launch_frames(game_hip_ctx* c, uint32_t frame0, uint32_t count, uint32_t slo
     P.vlut = c->vlut;
     P.slut = c->slut;
     void* args[] = {&P};
-    uint32_t gx = (c->w + 256u * c->shape.pixels_per_lane - 1u) / (256u * c->shape.pixels_per_lane);
+    uint32_t gx = (c->w + c->shape.wg * c->shape.pixels_per_lane - 1u) / (c->shape.wg * c->shape.pixels_per_lane);
     uint32_t gy = rows;   // one row per workgroup row; rows <= height <= 65535 is checked at creation
-    HIP_TRY(hipModuleLaunchKernel(c->fn, gx, gy, count, 256, 1, 1, c->lds_bytes, c->stream, args, nullptr));
+    HIP_TRY(hipModuleLaunchKernel(c->fn, gx, gy, count, c->shape.wg, 1, 1, c->lds_bytes, c->stream, args, nullptr));
     return GAME_OK;
 }
 
