@@ -4,26 +4,29 @@
     python bench.py --gpus N --steps K --warmup W [--config c2]
 
 Default workload (config c2) is the benchmark the metric is quoted on: the fbm showcase cinematic
-`domain_warp(0.1, 3.0) | fbm(3.0, octaves: 6, ...) | glow(1.5) | tint(...)` at 3840x2160, rendered
-as synthetic frame batches with u_time = k/60. One step = one batch of --batch frames rendered
-into the HBM frame ring (no read-back inside the timed region). With N > 1 (launched by
-torch.distributed.run, one rank per GPU) frames are sharded k mod N with no collective on the data
-path; per-GPU work is fixed, so scaling is weak. Rank 0 prints one JSON line.
+`domain_warp(0.1, 3.0) | fbm(3.0, octaves: 6, ...) | glow(1.5) | tint(...)` at 3840x2160, 1000 frames with
+u_time = k/60. One step = the whole job on each GPU: 1000 frames rendered into the HBM frame ring in ring-sized
+launches of 25 frames (no read-back inside the timed region). With N > 1 there is one process per GPU; frames are
+sharded k mod N with no collective on the data path and every GPU renders 1000 frames of an N x 1000 frame job, so
+scaling is weak. `python bench.py --gpus N` starts its N rank processes itself (before anything touches a GPU) unless
+a launcher (torch.distributed.run) already did. Rank 0 prints one JSON line.
 
-Other configs (c1, c2b, c3, c4, c5) exercise the remaining benchmark cinematics; c4 shards
-horizontal bands, c5 shards particle indices with an all-gather of positions per step.
+Other configs (c1, c2b, c3, c4, c5) exercise the remaining benchmark cinematics; c4 shards horizontal bands, c5 shards
+particle indices with an all-gather of positions per step. At N = 1 the default run also times each of them briefly
+after the headline and reports them under "other_configs".
 """
 import argparse
+import glob
+import importlib.util
 import json
 import os
+import subprocess
 import sys
 import time
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import conftest as T  # noqa: E402  (fixtures for the benchmark cinematics + loaders)
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X vector FP32 peak: 256 CU x 4 SIMD x 32 lanes x 2 (fma) x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
@@ -31,35 +34,69 @@ REHEARSE = os.environ.get("GAME_BENCH_REHEARSE") == "1"   # not a measurement mo
 SIMDS, CLOCK_HZ = 1024, 2.4e9     # 256 CUs x 4 SIMDs; one wave64 VALU instruction per 2 cycles per SIMD at best
 
 
-def measured_counters(key, frames_per_launch):
+def _load(name, path, package=False):
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, path, submodule_search_locations=[os.path.dirname(path)] if package else None)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_product():
+    """The product binding (game-engine_amd/__init__.py -> libgame_hip.so); raises when the library is missing."""
+    return _load("game_engine_amd", os.path.join(ROOT, "game-engine_amd", "__init__.py"), package=True)
+
+
+def load_oracle():
+    """The CPU restatement, only for the cpu_baseline leg and the parity spot check (never inside a timed GPU region)."""
+    return _load("game_oracle_binding", os.path.join(ROOT, "oracle", "binding.py")).Oracle()
+
+
+def measured_counters(key, frames_per_launch, kernel_hash):
     """HBM traffic and VALU instruction counts per launch from the committed rocprofv3 PMC summary
-    (profiles/r*_traffic.json, written from the output of tools/profile_bench.sh). The counters are
-    collected in separate profiler runs of this same command, so they are read back here instead of
-    being measured inside the timed run; None when the profile does not cover this launch shape."""
-    import glob
+    (profiles/r*_traffic.json, written from the output of tools/profile_bench.sh). The counters are collected in
+    separate profiler runs of this same command, so they are read back here instead of being measured inside the
+    timed run. The record carries the hash of the kernel it was measured on; a record for another kernel build or
+    another launch shape is ignored (None), so a stale profile never decorates a new kernel."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         try:
             rec = json.load(open(path)).get(key)
         except (OSError, ValueError):
             continue
-        if rec and rec.get("frames_per_launch") == frames_per_launch:
+        if rec and rec.get("frames_per_launch") == frames_per_launch and rec.get("kernel_hash") == kernel_hash:
+            rec["file"] = os.path.relpath(path, ROOT)
             return rec
     return None
 
-# Algorithmic work per pixel (flop convention: add/sub/mul/div/min/max/abs/floor/fract/compare/select
-# = 1, sin/cos/sqrt/atan = 1, mul+add pair = 2), summed over the stages of each cinematic.
-CONFIGS = {
-    "c1": dict(src=T.C1_HELLO, w=1024, h=1024, flops_px=47, bytes_px=4, bound="hbm", batch=200,
-               workload="examples/001-hello.game circle|glow|tint, 1024x1024"),
-    "c2": dict(src=T.C2_FBM, w=3840, h=2160, flops_px=1006, bytes_px=4, bound="valu",
-               workload="fbm showcase: domain_warp(0.1,3.0)|fbm(3.0,octaves:6,0.5,2.0)|glow(1.5)|tint, 3840x2160, frame-sharded"),
-    "c2b": dict(src=T.C2B_NOISE, w=3840, h=2160, flops_px=900, bytes_px=4, bound="valu",
-                workload="examples/tutorial-05-noise.game (fbm4 + simplex + voronoi, 3 layers), 3840x2160"),
-    "c3": dict(src=T.C3_SHOWCASE, w=3840, h=2160, flops_px=95, bytes_px=4, bound="hbm",
-               workload="examples/007-showcase.game spectrum|bloom|chromatic|vignette|grain, 3840x2160"),
-    "c4": dict(src=T.C4_TRAILS, w=7680, h=4320, flops_px=59, bytes_px=8, bound="hbm",
-               workload="examples/003-memory-trails.game feedback memory, 7680x4320, frame-serial, band-sharded"),
-}
+
+def spawn_ranks(n, argv):
+    """`--gpus N` without a launcher: start N rank processes (fresh interpreters, nothing here has touched a GPU),
+    one per GPU, rendezvous on 127.0.0.1; rank 0 prints the JSON line. Returns the worst exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + argv, env=env))
+    worst = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            rc = p.poll()
+            if rc is None:
+                continue
+            pending.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                for q in pending:       # a rank failed: the others would wait in a barrier for ever
+                    q.terminate()
+        time.sleep(0.05)
+    return worst
 
 
 def dist_setup(n_gpus):
@@ -69,15 +106,17 @@ def dist_setup(n_gpus):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if REHEARSE:
         local = 0       # rehearsal of the N > 1 control flow on a one-GPU box: every rank shares GPU 0, gloo rendezvous
+    if world != n_gpus:
+        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}")
     if world > 1:
         import torch.distributed as dist
+        if local >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: GPU {local} does not exist ({torch.cuda.device_count()} visible)")
         torch.cuda.set_device(local)
         if REHEARSE:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-    if world != n_gpus:
-        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run --nproc-per-node N")
     return torch, rank, world, local
 
 
@@ -98,11 +137,10 @@ def max_over_ranks(torch, world, value):
     return float(t.item())
 
 
-def cpu_baseline_frames(game, oracle, cin, cfg, seconds_budget=20.0):
-    """Times the oracle (CPU port of the same path) on whole frames of the same workload."""
+def cpu_baseline_frames(oracle, cin, cfg, rows, seconds_budget=20.0):
+    """Times the oracle (CPU port of the same path) on whole rows of the same workload."""
     threads = min(16, os.cpu_count() or 1)
     w, h = cfg["w"], cfg["h"]
-    rows = cin.uniform_rows([0.0], w, h)
     probe_rows = max(8, threads)
     t0 = time.time()
     oracle.render(cin.blob, w, h, rows[0], row0=0, rows=probe_rows, threads=threads)
@@ -118,116 +156,136 @@ def cpu_baseline_frames(game, oracle, cin, cfg, seconds_budget=20.0):
             "sample": f"{done} rows of {w} px of the same cinematic ({done * w / 1e6:.1f} Mpixel, {dt:.1f} s, {threads} threads)"}
 
 
-def run_frames(args, torch, rank, world, local, key):
-    cfg = CONFIGS[key]
-    game = T.load_product()
+def valu_roofline(pmc, sec, algorithmic_flops):
+    """Roofline record of a VALU-bound kernel. `frac` is the share of VALU issue slots the launch used: executed
+    wave64 VALU instructions (PMC SQ_INSTS_VALU per launch) x 2 cycles / (SIMDs x clock x launch time); `achieved`
+    is the same thing in the peak's unit, every issued instruction counted as a full-rate 64-lane fma
+    (128 flop): achieved / peak = frac. The algorithmic rate (operators of the emitted GLSL by the flop convention,
+    whether executed or read from a lattice table) is reported beside it and may exceed the arithmetic peak."""
+    alg = algorithmic_flops / sec / 1e12
+    out = {"bound": "valu", "achieved": None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+           "frac_definition": "VALU issue-slot occupancy: SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x clock_hz_assumed x launch time)",
+           "clock_hz_assumed": CLOCK_HZ, "algorithmic_tflops": round(alg, 2), "algorithmic_over_peak": round(alg / PEAK_FP32_TFLOPS, 4)}
+    if pmc:
+        insts = pmc["waves_per_launch"] * pmc["valu_instructions_per_wave"]
+        frac = insts * 2.0 / (SIMDS * CLOCK_HZ * sec)
+        out.update({"achieved": round(insts * 128.0 / sec / 1e12, 2), "frac": round(frac, 4),
+                    "traffic": round(pmc["traffic_bytes_per_launch"]), "valu_instructions_per_launch": round(insts),
+                    "valu_instructions_per_wave": round(pmc["valu_instructions_per_wave"], 1), "counters_from": pmc["file"]})
+    else:
+        out["note"] = "no committed PMC record matches this kernel build and launch shape: frac and traffic not available"
+    return out
+
+
+def time_frames(args, game, torch, rank, world, local, key, steps, warmup, extras):
+    """Times `steps` passes of workload `key` on this rank's GPU; returns the bench record (roofline on rank 0)."""
+    W = game.workloads
+    cfg = W.CONFIGS[key]
     cin = game.compile(cfg["src"]).cinematics[0]
     w, h = cfg["w"], cfg["h"]
     banded = cin.uses_memory
-    batch = args.batch if args.batch else cfg.get("batch", 25)
+    frames = args.frames if args.frames else cfg["frames"]          # frames per step on this GPU
+    batch = min(args.batch if args.batch else cfg["batch"], frames)  # frames per launch (stateless cinematics)
     if banded:
         # horizontal bands, multiples of 8 rows; every rank renders every frame of its band. The
         # feedback read is the same pixel of the previous frame, so no halo rows are exchanged.
-        from game_engine_amd import distributed
-        row0, nrows = distributed.band_for_rank(h, rank, world)
+        row0, nrows = game.distributed.band_for_rank(h, rank, world)
+        ks = list(range(frames))
     else:
         row0, nrows = 0, h
+        ks = [i * world + rank for i in range(frames)]               # frame k -> GPU k mod N
+    t_create = time.perf_counter()
     r = cin.renderer(w, h, device=local)
-    r.set_ring(2 if banded else batch)      # stateless: one launch per step covers the whole batch
+    create_ms = (time.perf_counter() - t_create) * 1e3
+    compile_ms, tables_ms = r.setup_ms()
+    r.set_ring(2 if banded else batch)
+    table = W.frame_rows(cin, key, ks, w, h)
 
-    def rows_for(step):
+    def step():
         if banded:
-            ks = [step * batch + i for i in range(batch)]
+            r.render_band(table, row0, nrows, readback=False)
         else:
-            ks = [(step * batch + i) * world + rank for i in range(batch)]           # frame k -> GPU k mod N
-        bass = [0.5 + 0.5 * np.sin(2 * np.pi * 0.5 * k / 60.0) for k in ks]
-        audio = {"bass": bass} if key == "c4" else ({"bass": 0.8, "mid": 0.6, "treble": 0.4, "energy": 0.6} if key == "c3" else None)
-        return cin.uniform_rows([k / 60.0 for k in ks], w, h, audio=audio)
+            r.render(table, readback=False)
 
-    tables = [rows_for(s) for s in range(args.warmup + args.steps)]
-
-    def step(s):
-        if banded:
-            r.render_band(tables[s], row0, nrows, readback=False)
-        else:
-            r.render(tables[s], readback=False)
-
-    for s in range(args.warmup):
-        step(s)
+    for _ in range(warmup):
+        step()
     r.sync()
     kernel_ms, launches = 0.0, 0
     barrier(torch, world)
     t0 = time.perf_counter()
     if args.events:
         r.timing_begin()                    # one HIP event pair per step on the render stream; nothing waits in between
-    for s in range(args.warmup, args.warmup + args.steps):
-        step(s)
+    for _ in range(steps):
+        step()
     r.sync()
     barrier(torch, world)
     dt = max_over_ranks(torch, world, time.perf_counter() - t0)
     if args.events:
         kernel_ms, launches = r.timing_end()
 
-    frames_total = args.steps * batch * (1 if banded else world)
-    pixels_total = frames_total * w * h
-    value = pixels_total / dt / 1e6
+    frames_total = steps * frames * (1 if banded else world)
+    value = frames_total * w * h / dt / 1e6
     out = {
         "metric": "Mpixel/s at 3840x2160 (fbm showcase)" if key == "c2" else f"Mpixel/s ({key})",
-        "value": round(value, 1), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if banded else "weak",
+        "value": round(value, 1), "unit": "Mpixel/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if banded else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": cfg["workload"], "frames_per_step": batch, "width": w, "height": h,
+        "config": {"workload": cfg["workload"], "frames_per_step": frames, "frames_per_launch": 1 if banded else batch,
+                   "job_frames_per_step": frames * (1 if banded else world), "width": w, "height": h,
                    "parallelism": f"bands{world}" if banded else f"frames{world}", "output": "RGBA8 frames in an HBM ring"},
+        "timed_region_s": round(dt, 4),
     }
-    if rank == 0:
-        if args.events and launches:
-            px_launch = (nrows if banded else h) * w * (1 if banded else batch)
-            sec = kernel_ms / launches / 1e3
-            pmc = measured_counters(key, 1 if banded else batch) if world == 1 else None
-            traffic = round(pmc["traffic_bytes_per_launch"]) if pmc else None
-            if cfg["bound"] == "valu":
-                ach = px_launch * cfg["flops_px"] / sec / 1e12
-                out["roofline"] = {"bound": "valu", "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-                                   "kernel": "game_frame", "avg_launch_ms": round(sec * 1e3, 4), "pixels_per_launch": px_launch,
-                                   "flops_per_pixel": cfg["flops_px"]}
-            else:
-                ach = px_launch * cfg["bytes_px"] / sec / 1e9
-                out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
-                                   "kernel": "game_frame", "avg_launch_ms": round(sec * 1e3, 4), "pixels_per_launch": px_launch,
-                                   "bytes_per_pixel": cfg["bytes_px"]}
-            if cfg["bound"] == "valu" and not os.environ.get("GAME_HIP_NO_LUT"):
-                out["roofline"]["note"] = ("lattice hashes / voronoi points are read from per-device tables, so the algorithmic flop rate "
-                                           "can exceed the arithmetic peak; valu_issue_frac is the share of VALU issue slots actually used; "
-                                           "arithmetic_only is the same kernel built without the tables")
-                if world == 1 and not args.no_cpu:   # comparison legs are skipped together (--no-cpu: profiler runs)
-                    # the same workload with every hash evaluated arithmetically (no tables), a few steps, outside the main timing
-                    os.environ["GAME_HIP_NO_LUT"] = "1"
-                    r2 = cin.renderer(w, h, device=local)
-                    os.environ.pop("GAME_HIP_NO_LUT")
-                    r2.set_ring(batch)
-                    for s2 in range(3):
-                        r2.render(tables[s2 % len(tables)], readback=False)
-                    r2.sync()
-                    ms2, n2 = 0.0, 10
-                    for s2 in range(n2):
-                        r2.render(tables[s2 % len(tables)], readback=False)
-                        ms2 += r2.last_kernel_ms()[0]
-                    r2.close()
-                    sec2 = ms2 / n2 / 1e3
-                    ach2 = px_launch * cfg["flops_px"] / sec2 / 1e12
-                    out["roofline"]["arithmetic_only"] = {"value": round(px_launch / sec2 / 1e6, 1), "unit": "Mpixel/s", "achieved": round(ach2, 2),
-                                                          "frac": round(ach2 / PEAK_FP32_TFLOPS, 4), "avg_launch_ms": round(sec2 * 1e3, 4)}
+    if rank == 0 and args.events and launches:
+        per_launch_frames = 1 if banded else batch
+        px_launch = (nrows if banded else h) * w * per_launch_frames
+        sec = kernel_ms / launches / 1e3
+        pmc = measured_counters(key, per_launch_frames, r.kernel_hash) if world == 1 else None
+        if cfg["bound"] == "valu":
+            roof = valu_roofline(pmc, sec, px_launch * cfg["flops_px"])
+            roof["flops_per_pixel"] = cfg["flops_px"]
+        else:
+            ach = px_launch * cfg["bytes_px"] / sec / 1e9
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+                    "traffic": round(pmc["traffic_bytes_per_launch"]) if pmc else None, "bytes_per_pixel": cfg["bytes_px"]}
             if pmc:
-                # share of the VALU issue slots (one wave64 instruction per 2 cycles per SIMD) this launch used
-                out["roofline"]["valu_issue_frac"] = round(pmc["waves_per_launch"] * pmc["valu_instructions_per_wave"] * 2.0 / (SIMDS * CLOCK_HZ * sec), 4)
-                out["roofline"]["valu_instructions_per_wave"] = round(pmc["valu_instructions_per_wave"], 1)
-        if world == 1 and not args.no_cpu:
-            oracle = T.Oracle()
-            out["cpu_baseline"] = cpu_baseline_frames(game, oracle, cin, cfg, args.cpu_seconds)
+                insts = pmc["waves_per_launch"] * pmc["valu_instructions_per_wave"]
+                roof["valu_issue_frac"] = round(insts * 2.0 / (SIMDS * CLOCK_HZ * sec), 4)
+                roof["valu_instructions_per_pixel"] = round(insts * 64.0 / px_launch, 1)
+        roof.update({"kernel": "game_frame", "kernel_hash": r.kernel_hash, "avg_launch_ms": round(sec * 1e3, 4),
+                     "pixels_per_launch": px_launch, "launches_timed": launches})
+        out["roofline"] = roof
+        out["setup"] = {"context_create_ms": round(create_ms, 1), "kernel_compile_ms": round(compile_ms, 1), "table_build_ms": round(tables_ms, 1)}
+    if rank == 0 and world == 1 and extras:
+        if cfg["bound"] == "valu" and not os.environ.get("GAME_HIP_NO_LUT") and "roofline" in out:
+            # the same workload with every hash evaluated arithmetically (no tables), a few launches, outside the main timing
+            os.environ["GAME_HIP_NO_LUT"] = "1"
+            r2 = cin.renderer(w, h, device=local)
+            os.environ.pop("GAME_HIP_NO_LUT")
+            r2.set_ring(batch)
+            r2.render(table[:batch], readback=False)
+            r2.sync()
+            r2.render(table[:10 * batch], readback=False)
+            ms2, n2 = r2.last_kernel_ms()
+            r2.close()
+            sec2 = ms2 / n2 / 1e3
+            ach2 = px_launch * cfg["flops_px"] / sec2 / 1e12
+            out["roofline"]["arithmetic_only"] = {"value": round(px_launch / sec2 / 1e6, 1), "unit": "Mpixel/s", "algorithmic_tflops": round(ach2, 2),
+                                                  "algorithmic_over_peak": round(ach2 / PEAK_FP32_TFLOPS, 4), "avg_launch_ms": round(sec2 * 1e3, 4),
+                                                  "note": "same kernel built without the lattice tables (every hash computed)"}
+        if not banded:
+            # the same path with every frame also delivered to page-locked host memory (never the headline value)
+            nf = min(8, batch)
+            host = game.pinned_array((nf, h, w, 4))
+            r.render(table[:nf], out=host)
+            t1 = time.perf_counter()
+            r.render(table[:nf], out=host)
+            out["pcie_inclusive_mpixel_s"] = round(nf * w * h / (time.perf_counter() - t1) / 1e6, 1)
+            del host
+        if not args.no_cpu:
+            oracle = load_oracle()
+            out["cpu_baseline"] = cpu_baseline_frames(oracle, cin, cfg, table, args.cpu_seconds)
             # parity spot check outside the timed region: a band of the last frame against the oracle
-            last = tables[-1][-1:]
+            last = table[-1:]
             r.reset_memory()
             got = r.render_band(last, h // 2 - 2, 4)[0]
             want = oracle.render(cin.blob, w, h, last[0], row0=h // 2 - 2, rows=4)
@@ -236,25 +294,19 @@ def run_frames(args, torch, rank, world, local, key):
     return out
 
 
-def run_particles(args, torch, rank, world, local):
-    game = T.load_product()
-    cin = game.compile(T.C5_GRAVITY).cinematics[0]
-    n = args.particles
-    from game_engine_amd import distributed
-    first, count = distributed.particle_range(n, rank, world)
+def time_particles(args, game, torch, rank, world, local, n, steps, warmup, extras):
+    cin = game.compile(game.workloads.C5_GRAVITY).cinematics[0]
+    first, count = game.distributed.particle_range(n, rank, world)
     r = cin.renderer(16, 16, device=local)
     r.particles_seed(n)
-    gather = None
-    if world > 1:
-        from game_engine_amd import distributed
-        gather = distributed.PositionExchange(r, n, first, count, torch)
+    gather = game.distributed.PositionExchange(r, n, first, count, torch) if world > 1 else None
 
     def step():
         r.particles_step(1 / 60.0, 1, first=first, count=count)
         if gather:
             gather.exchange()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     r.sync()
     kernel_ms, launches = 0.0, 0
@@ -262,27 +314,38 @@ def run_particles(args, torch, rank, world, local):
     t0 = time.perf_counter()
     if args.events:
         r.timing_begin()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
+    if gather:
+        gather.finish()
     r.sync()
     barrier(torch, world)
     dt = max_over_ranks(torch, world, time.perf_counter() - t0)
     if args.events:
         kernel_ms, launches = r.timing_end()
-    pairs = float(n) * (n - 1) * args.steps
+    pairs = float(n) * (n - 1) * steps
     out = {"metric": "Mpair/s (gravity all-pairs)", "value": round(pairs / dt / 1e6, 1), "unit": "Mpair/s", "n_gpus": world,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+           "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"examples/010-gravity-particles.game, {n} particles, all-pairs, dt=1/60", "particles": n,
-                      "parallelism": f"index{world}"}}
+                      "parallelism": f"index{world}"},
+           "timed_region_s": round(dt, 4)}
     if rank == 0 and args.events and launches:
         sec = kernel_ms / launches / 1e3
-        ach = (20.0 * count * (n - 1) + 12.0 * count) / sec / 1e12
-        out["roofline"] = {"bound": "valu", "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None, "kernel": "game_gravity",
-                           "avg_launch_ms": round(sec * 1e3, 4)}
-    if rank == 0 and world == 1 and not args.no_cpu:
-        oracle = T.Oracle()
+        flops = 20.0 * count * (n - 1) + 12.0 * count
+        pmc = measured_counters("c5", n, r.kernel_hash) if world == 1 else None
+        roof = valu_roofline(pmc, sec, flops)
+        # for the particle kernel the flop convention (20 per pair) is below the arithmetic peak by construction, so
+        # it stays the headline fraction; the issue-slot occupancy is reported beside it
+        if roof["frac"] is not None:
+            roof["valu_issue_frac"] = roof["frac"]
+        roof.update({"achieved": roof["algorithmic_tflops"], "frac": roof["algorithmic_over_peak"],
+                     "frac_definition": "20 flop per pair + 12 per particle, over the FP32 vector peak",
+                     "kernel": "game_gravity", "kernel_hash": r.kernel_hash, "avg_launch_ms": round(sec * 1e3, 4), "flops_per_pair": 20})
+        roof.pop("note", None)
+        out["roofline"] = roof
+    if rank == 0 and world == 1 and extras and not args.no_cpu:
+        oracle = load_oracle()
         threads = min(16, os.cpu_count() or 1)
         m = min(n, 16384)
         p = oracle.seed_particles(m)
@@ -295,23 +358,46 @@ def run_particles(args, torch, rank, world, local):
     return out
 
 
+def brief(rec):
+    """The part of a bench record kept per entry of "other_configs"."""
+    keep = {k: rec[k] for k in ("value", "unit", "steps", "ms_per_step", "timed_region_s") if k in rec}
+    keep["workload"] = rec["config"]["workload"]
+    if "roofline" in rec:
+        keep["roofline"] = {k: v for k, v in rec["roofline"].items() if k not in ("frac_definition", "note", "arithmetic_only")}
+    return keep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS) + ["c5"])
-    ap.add_argument("--batch", type=int, default=0, help="frames per step (per GPU); default 25 (200 for the 1024x1024 config)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c2b", "c3", "c4", "c5"])
+    ap.add_argument("--frames", type=int, default=0, help="frames per step on each GPU; default = the whole job of the config (c2: 1000)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per launch; default 25 (200 for the 1024x1024 config)")
     ap.add_argument("--particles", type=int, default=1048576)
     ap.add_argument("--no-events", dest="events", action="store_false", help="skip per-step HIP event timing")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-others", action="store_true", help="skip the brief runs of the other configs after the headline")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     torch, rank, world, local = dist_setup(args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local)
-    out = run_particles(args, torch, rank, world, local) if args.config == "c5" else run_frames(args, torch, rank, world, local, args.config)
+    game = load_product()
+    if args.config == "c5":
+        out = time_particles(args, game, torch, rank, world, local, args.particles, args.steps, args.warmup, True)
+    else:
+        out = time_frames(args, game, torch, rank, world, local, args.config, args.steps, args.warmup, True)
+    if rank == 0 and world == 1 and args.config == "c2" and not args.no_others and not args.frames and not args.batch:
+        others = {}
+        for key, steps in (("c1", 10), ("c2b", 5), ("c3", 10), ("c4", 3)):
+            others[key] = brief(time_frames(args, game, torch, rank, world, local, key, steps, 1, False))
+        others["c5"] = brief(time_particles(args, game, torch, rank, world, local, 1048576, 3, 1, False))
+        out["other_configs"] = others
     if rank == 0:
         if REHEARSE:
             out["data"] = "synthetic (REHEARSAL: all ranks on one GPU, not a measurement)"

@@ -5,9 +5,11 @@ list_builtins) plus the GPU render path that replaces its browser runtime. Nothi
 pixels: every call goes to the shared library, and a missing library or a missing GPU raises.
 """
 import ctypes
+import importlib.util
 import json
 import os
 import struct
+import sys
 
 import numpy as np
 
@@ -30,6 +32,16 @@ class GameError(RuntimeError):
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make -C game-engine_amd` (or __graft_entry__.build())")
+    # One HIP runtime per process. PyTorch-ROCm ships a private copy of libamdhip64 that it asks for by a name
+    # (libamdhip64.so) the system copy's soname (libamdhip64.so.7) does not satisfy, so a process that loads this
+    # library first and torch later ends up with two runtimes, and the second finds no GPU. When torch is installed
+    # but not imported yet, its copy is loaded here first: libgame_hip.so then binds to it by soname, and a later
+    # `import torch` finds the same file already loaded. Without torch the system runtime is used.
+    if "torch" not in sys.modules:
+        spec = importlib.util.find_spec("torch")
+        shared = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else ""
+        if shared and os.path.exists(shared):
+            ctypes.CDLL(shared, mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(LIB_PATH)
     c = ctypes
     vp, sz, u32, u64, f32 = c.c_void_p, c.c_size_t, c.c_uint32, c.c_uint64, c.c_float
@@ -87,6 +99,10 @@ def _load():
         "game_hip_ring_frames": (u32, [vp]),
         "game_hip_last_kernel_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(u32)]),
         "game_hip_kernel_source": (c.c_char_p, [vp]),
+        "game_hip_device_header_source": (c.c_char_p, []),
+        "game_hip_gravity_source": (c.c_char_p, [vp]),
+        "game_hip_stream": (vp, [vp]),
+        "game_hip_setup_ms": (c.c_int, [vp, c.POINTER(f32), c.POINTER(f32)]),
         "game_hip_compile_only": (c.c_int, [vp, c.POINTER(sz)]),
         "game_hip_compile_only_ex": (c.c_int, [vp, u32, c.POINTER(sz)]),
         "game_hip_dump_code": (c.c_int, [vp, c.c_char_p]),
@@ -402,13 +418,16 @@ class Renderer:
             raise ValueError(f"uniform rows need {self.cinematic.frame_floats} floats, got {rows.shape[1]}")
         return rows
 
-    def render(self, rows, readback=True, pinned=False):
+    def render(self, rows, readback=True, pinned=False, out=None):
         """Renders len(rows) frames; returns (nframes, h, w, 4) uint8 (top row first) or None. pinned=True
-        reads back into page-locked host memory (freed with the returned array)."""
+        reads back into page-locked host memory (freed with the returned array); out= a caller's array of that shape."""
         rows = self._rows(rows)
         shape = (rows.shape[0], self.h, self.w, 4)
-        out = (pinned_array(shape) if pinned else np.empty(shape, dtype=np.uint8)) if readback else None
-        _check(lib.game_hip_render(self._h, rows.ctypes.data, rows.shape[0], out.ctypes.data if readback else None))
+        if out is not None:
+            assert out.dtype == np.uint8 and out.shape == shape and out.flags["C_CONTIGUOUS"]
+        elif readback:
+            out = pinned_array(shape) if pinned else np.empty(shape, dtype=np.uint8)
+        _check(lib.game_hip_render(self._h, rows.ctypes.data, rows.shape[0], None if out is None else out.ctypes.data))
         return out
 
     def render_band(self, rows, row0, nrows, readback=True):
@@ -451,6 +470,23 @@ class Renderer:
     @property
     def kernel_source(self):
         return lib.game_hip_kernel_source(self._h).decode()
+
+    @property
+    def kernel_hash(self):
+        """Identifies the kernel build: sha256 over the generated source and the device-function header it includes."""
+        import hashlib
+        return hashlib.sha256(lib.game_hip_kernel_source(self._h) + b"\0" + lib.game_hip_gravity_source(self._h) + b"\0" +
+                              lib.game_hip_device_header_source()).hexdigest()[:16]
+
+    def stream_ptr(self):
+        """The context's hipStream_t as an integer (for torch.cuda.ExternalStream)."""
+        return lib.game_hip_stream(self._h)
+
+    def setup_ms(self):
+        """(hiprtc compile ms, lattice-table build ms) spent creating this context."""
+        a, b = ctypes.c_float(), ctypes.c_float()
+        _check(lib.game_hip_setup_ms(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     # particles (reference: GameGravitySim, game-compiler/src/codegen/gravity.rs:123-191)
     def particles_init(self, pos_xy, vel_xy=None):
@@ -513,3 +549,7 @@ def parse_blob(blob):
     out = dict(zip(keys, hdr))
     out["name"] = out["name"].split(b"\0")[0].decode()
     return out
+
+
+from . import distributed  # noqa: E402,F401  (partition rules and exchange steps for N > 1 GPUs)
+from . import workloads  # noqa: E402,F401  (benchmark cinematics and their synthetic inputs)

@@ -8,6 +8,7 @@
 #include "codegen.hpp"
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -51,6 +52,7 @@ struct game_hip_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<TimedCall> ev_pending;
     bool timing = false;
+    bool own_recorded = false;   // ev_own0 / ev_own1 hold a completed pair (a call outside a timing section recorded them)
     float last_ms = 0.0f;
     uint32_t last_launches = 0;
     // particles
@@ -64,6 +66,7 @@ struct game_hip_ctx {
     float* vy = nullptr;
     int cur = 0;
     float sim_time = 0.0f;
+    float compile_ms = 0.0f, tables_ms = 0.0f;   // host time game_hip_create spent in hiprtc / building lattice tables
 };
 
 namespace {
@@ -86,6 +89,11 @@ struct GravityParams {
     uint32_t n, first, count, pad;
     float dt, time;
 };
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 int hip_fail(const char* what, hipError_t e)
 {
@@ -225,8 +233,15 @@ float host_fract(float x)
 int ensure_ring(game_hip_ctx* c, uint32_t ring)
 {
     if (c->frames && c->ring == ring) return GAME_OK;
+    // reject a ring whose byte count does not fit the device before anything is released
+    const unsigned long long frame_bytes = (unsigned long long)c->w * c->h * 4ull;
+    size_t dev_free = 0, dev_total = 0;
+    HIP_TRY(hipMemGetInfo(&dev_free, &dev_total));
+    if ((unsigned long long)ring > (unsigned long long)dev_total / frame_bytes)
+        return set_error(GAME_E_ARGUMENT, "game_hip_set_ring: " + std::to_string(ring) + " frames of " + std::to_string(frame_bytes) +
+                                              " bytes exceed the device's memory (" + std::to_string(dev_total) + " bytes)");
     if (c->frames) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->frames)); c->frames = nullptr; c->ring = 0; }
-    size_t bytes = (size_t)ring * c->w * c->h * 4;
+    size_t bytes = (size_t)ring * frame_bytes;
     HIP_TRY(hipMalloc((void**)&c->frames, bytes));
     HIP_TRY(hipMemsetAsync(c->frames, 0, bytes, c->stream));
     c->ring = ring;
@@ -235,18 +250,25 @@ int ensure_ring(game_hip_ctx* c, uint32_t ring)
     return GAME_OK;
 }
 
-int upload_rows(game_hip_ctx* c, const float* uniforms, uint32_t nframes)
+// The kernel's frame rows: the caller's floats, then the two values the shader derives once per frame, then (animate
+// shapes) the values of the expression-valued stage arguments.
+void build_rows(const game_hip_ctx* c, const float* uniforms, uint32_t nframes, float* out)
 {
-    size_t need = (size_t)nframes * c->ustride;
-    c->utab_host.resize(need);
     for (uint32_t f = 0; f < nframes; ++f) {
         const float* src = uniforms + (size_t)f * c->row_floats;
-        float* dst = c->utab_host.data() + (size_t)f * c->ustride;
+        float* dst = out + (size_t)f * c->ustride;
         memcpy(dst, src, (size_t)c->row_floats * 4);
         dst[c->shape.time_slot] = host_fract(src[BU_TIME] / 120.0f) * 120.0f;   // glsl.rs:56
         dst[c->shape.aspect_slot] = src[BU_RES_X] / src[BU_RES_Y];              // glsl.rs:55
         if (c->shape.animate) eval_derived(c->ir, src, dst + c->shape.derived_slot);
     }
+}
+
+int upload_rows(game_hip_ctx* c, const float* uniforms, uint32_t nframes)
+{
+    size_t need = (size_t)nframes * c->ustride;
+    c->utab_host.resize(need);
+    build_rows(c, uniforms, nframes, c->utab_host.data());
     if (need > c->utab_cap) {
         if (c->utab_dev) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->utab_dev)); c->utab_dev = nullptr; c->utab_cap = 0; }
         size_t cap = need < 4096 ? 4096 : need;
@@ -257,18 +279,19 @@ int upload_rows(game_hip_ctx* c, const float* uniforms, uint32_t nframes)
     return GAME_OK;
 }
 
-int launch_frames(game_hip_ctx* c, uint32_t frame0, uint32_t count, uint32_t slot0, const uint32_t* prev, uint32_t row0,
-                  uint32_t rows)
+// Frames [frame0, frame0 + count) of the uploaded rows `utab` into slots slot0.. of the `ring`-slot frame array `out`.
+int launch_frames_into(game_hip_ctx* c, uint32_t* out, uint32_t ring, const float* utab, uint32_t frame0, uint32_t count, uint32_t slot0,
+                       const uint32_t* prev, uint32_t row0, uint32_t rows)
 {
     // the kernel wraps slot0 + frame index with one conditional subtract
-    if (count == 0 || count > c->ring || slot0 >= c->ring) return set_error(GAME_E_ARGUMENT, "launch_frames: frame batch does not fit the ring");
+    if (count == 0 || count > ring || slot0 >= ring) return set_error(GAME_E_ARGUMENT, "launch_frames: frame batch does not fit the ring");
     FrameParams P;
-    P.out = c->frames;
+    P.out = out;
     P.prev = prev;
-    P.utab = c->utab_dev;
+    P.utab = utab;
     P.frame_pixels = (unsigned long long)c->w * c->h;
     P.w = c->w; P.h = c->h; P.row0 = row0; P.rows = rows;
-    P.ustride = c->ustride; P.slot0 = slot0; P.ring = c->ring; P.frame0 = frame0;
+    P.ustride = c->ustride; P.slot0 = slot0; P.ring = ring; P.frame0 = frame0;
     P.inv_w = 1.0f / (float)c->w;
     P.inv_h = 1.0f / (float)c->h;
     P.lut = c->lut;
@@ -279,6 +302,12 @@ int launch_frames(game_hip_ctx* c, uint32_t frame0, uint32_t count, uint32_t slo
     uint32_t gy = rows;   // one row per workgroup row; rows <= height <= 65535 is checked at creation
     HIP_TRY(hipModuleLaunchKernel(c->fn, gx, gy, count, c->shape.wg, 1, 1, c->lds_bytes, c->stream, args, nullptr));
     return GAME_OK;
+}
+
+int launch_frames(game_hip_ctx* c, uint32_t frame0, uint32_t count, uint32_t slot0, const uint32_t* prev, uint32_t row0,
+                  uint32_t rows)
+{
+    return launch_frames_into(c, c->frames, c->ring, c->utab_dev, frame0, count, slot0, prev, row0, rows);
 }
 
 // Picks the event pair for the call that is starting.
@@ -299,7 +328,22 @@ int begin_call_events(game_hip_ctx* c)
 void end_call_events(game_hip_ctx* c)
 {
     if (c->timing) c->ev_pending.push_back({c->ev0, c->ev1, c->last_launches});
+    else c->own_recorded = true;
 }
+// Between begin_call_events and end_call_events: a call that fails on the way hands its event pair back to the pool
+// (inside a timing section the pair would otherwise belong to neither the pool nor the pending list).
+struct CallEvents {
+    game_hip_ctx* c;
+    bool done = false;
+    explicit CallEvents(game_hip_ctx* ctx) : c(ctx) {}
+    void finish() { end_call_events(c); done = true; }
+    ~CallEvents()
+    {
+        if (done) return;
+        if (c->timing) { c->ev_pool.emplace_back(c->ev0, c->ev1); c->ev0 = c->ev_own0; c->ev1 = c->ev_own1; }
+        else c->own_recorded = false;   // the context's own pair may hold a start without an end
+    }
+};
 
 int render_impl(game_hip_ctx* c, const float* uniforms, uint32_t nframes, uint32_t row0, uint32_t rows, uint8_t* host)
 {
@@ -315,6 +359,7 @@ int render_impl(game_hip_ctx* c, const float* uniforms, uint32_t nframes, uint32
     c->last_launches = 0;
     rc = begin_call_events(c);
     if (rc) return rc;
+    CallEvents events(c);
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (c->ir.uses_memory) {
         // frame-serial: frame k reads the slot frame k-1 was written to
@@ -352,7 +397,7 @@ int render_impl(game_hip_ctx* c, const float* uniforms, uint32_t nframes, uint32
         }
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    end_call_events(c);
+    events.finish();
     if (host) HIP_TRY(hipStreamSynchronize(c->stream));
     return GAME_OK;
 }
@@ -445,7 +490,9 @@ int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int d
     c->ustride = c->row_floats + 2 + (c->shape.animate ? (uint32_t)c->ir.derived.size() : 0u);
     c->source = generate_frame_kernel(c->ir, c->shape);
     std::vector<char> code;
+    double t0 = now_ms();
     int rc = compile_hip(c->source, "game_frame.hip", code);
+    c->compile_ms = (float)(now_ms() - t0);
     if (rc) { delete c; return rc; }
     auto fail = [&](const char* what, hipError_t err) { int r = hip_fail(what, err); game_hip_destroy(c); return r; };
     if ((e = hipModuleLoadData(&c->mod, code.data())) != hipSuccess) return fail("hipModuleLoadData", e);
@@ -456,6 +503,7 @@ int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int d
     c->ev0 = c->ev_own0; c->ev1 = c->ev_own1;
     rc = ensure_ring(c, c->ir.uses_memory ? 2u : 4u);
     if (rc) { game_hip_destroy(c); return rc; }
+    t0 = now_ms();
     if (uses_lattice_noise(c->ir) && !getenv("GAME_HIP_NO_LUT")) {   // the variable is a tuning hook
         rc = lut_for_current_device(0, &c->lut);
         if (rc) { game_hip_destroy(c); return rc; }
@@ -475,9 +523,12 @@ int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int d
         rc = lut_for_current_device(2, &c->slut);
         if (rc) { game_hip_destroy(c); return rc; }
     }
+    c->tables_ms = (float)(now_ms() - t0);
     if (c->ir.gravity.present) {
         c->gsource = generate_gravity_kernel(c->ir);
+        t0 = now_ms();
         rc = compile_hip(c->gsource, "game_gravity.hip", code);
+        c->compile_ms += (float)(now_ms() - t0);
         if (rc) { game_hip_destroy(c); return rc; }
         if ((e = hipModuleLoadData(&c->gmod, code.data())) != hipSuccess) return fail("hipModuleLoadData(gravity)", e);
         if ((e = hipModuleGetFunction(&c->gfn, c->gmod, "game_gravity")) != hipSuccess) return fail("hipModuleGetFunction(gravity)", e);
@@ -584,6 +635,10 @@ int game_hip_last_kernel_ms(game_hip_ctx* c, float* ms, uint32_t* launches)
 {
     if (!c || !ms) return set_error(GAME_E_ARGUMENT, "game_hip_last_kernel_ms: null argument");
     HIP_TRY(hipSetDevice(c->device));
+    // nothing timed yet (no call so far, the last one failed, or the last timed call's pair was handed back by
+    // game_hip_timing_end): zero time over zero launches rather than an error from an unrecorded event
+    const bool own = c->ev0 == c->ev_own0;
+    if (own && !c->own_recorded) { *ms = 0.0f; if (launches) *launches = 0; return GAME_OK; }
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
     if (launches) *launches = c->last_launches;
@@ -638,6 +693,17 @@ void game_hip_host_free(void* p)
 }
 
 const char* game_hip_kernel_source(const game_hip_ctx* c) { return c ? c->source.c_str() : ""; }
+const char* game_hip_gravity_source(const game_hip_ctx* c) { return c ? c->gsource.c_str() : ""; }
+const char* game_hip_device_header_source(void) { return kDeviceHeader; }
+void* game_hip_stream(game_hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int game_hip_setup_ms(const game_hip_ctx* c, float* compile_ms, float* tables_ms)
+{
+    if (!c) return set_error(GAME_E_ARGUMENT, "game_hip_setup_ms: null context");
+    if (compile_ms) *compile_ms = c->compile_ms;
+    if (tables_ms) *tables_ms = c->tables_ms;
+    return GAME_OK;
+}
 
 // ── particles ────────────────────────────────────────────────────────────────────────────
 static int alloc_particles(game_hip_ctx* c, uint32_t n)
@@ -679,12 +745,15 @@ int game_hip_particles_init(game_hip_ctx* c, uint32_t n, const float* pos_xy, co
     size_t bytes = (size_t)n * 4;
     c->cur = 0;
     c->sim_time = 0.0f;
-    HIP_TRY(hipMemcpy(c->px[0], x.data(), bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->py[0], y.data(), bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->px[1], x.data(), bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->py[1], y.data(), bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->vx, vx.data(), bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->vy, vy.data(), bytes, hipMemcpyHostToDevice));
+    // The uploads go through the context's own stream: it does not synchronise with the null stream, and steps queued
+    // by an earlier game_hip_particles_step may still be reading and writing these arrays.
+    HIP_TRY(hipMemcpyAsync(c->px[0], x.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->py[0], y.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->px[1], x.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->py[1], y.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->vx, vx.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->vy, vy.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // the host vectors go away
     return GAME_OK;
 }
 
@@ -714,6 +783,7 @@ int game_hip_particles_step(game_hip_ctx* c, float dt, uint32_t steps, uint32_t 
     HIP_TRY(hipSetDevice(c->device));
     c->last_launches = 0;
     { int erc = begin_call_events(c); if (erc) return erc; }
+    CallEvents events(c);
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     for (uint32_t s = 0; s < steps; ++s) {
         c->sim_time = c->sim_time + dt;   // `_time += dt` before the dispatch (gravity.rs:158)
@@ -729,7 +799,7 @@ int game_hip_particles_step(game_hip_ctx* c, float dt, uint32_t steps, uint32_t 
         c->cur = 1 - c->cur;
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    end_call_events(c);
+    events.finish();
     return GAME_OK;
 }
 

@@ -38,19 +38,28 @@ def particle_range(n, rank, world):
     return first, max(0, min(n, first + per) - first)
 
 
-def gather_ranges(full, ranges, dist, group=None):
-    """Makes `full` (1-D tensor, identical length on every rank) consistent: rank r's range
-    ranges[r] = (first, count) is broadcast from r. Equal ranges use one all-gather."""
+def gather_ranges(full, ranges, dist, group=None, scratch=None):
+    """Makes `full` (1-D tensor, identical length on every rank) consistent: afterwards rank r's range
+    ranges[r] = (first, count) holds rank r's values everywhere. One all-gather whatever the split: the ranges of
+    particle_range() are `per` long except the last ones, so every rank sends a `per`-long buffer (its values, then
+    padding) and the gathered world * per values are the full array followed by padding.
+    scratch: optional (send, recv) tensors of per and world * per elements to reuse between calls."""
     world = len(ranges)
-    counts = {c for _, c in ranges}
     rank = dist.get_rank(group)
-    if len(counts) == 1 and ranges[0][1] * world == full.numel():
-        first, count = ranges[rank]
-        dist.all_gather_into_tensor(full, full[first:first + count].clone(), group=group)
+    per = max(c for _, c in ranges)
+    n = full.numel()
+    if any(f != min(n, r * per) for r, (f, _) in enumerate(ranges)) or sum(c for _, c in ranges) != n:
+        raise ValueError("gather_ranges: ranges must be the contiguous split of particle_range()")
+    first, count = ranges[rank]
+    if per * world == n:                       # even split: gather straight into the array
+        send = scratch[0] if scratch else full.new_empty(per)
+        send.copy_(full[first:first + count])
+        dist.all_gather_into_tensor(full, send, group=group)
         return
-    for r, (first, count) in enumerate(ranges):
-        if count:
-            dist.broadcast(full[first:first + count], src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+    send, recv = scratch if scratch else (full.new_zeros(per), full.new_empty(per * world))
+    send[:count].copy_(full[first:first + count])
+    dist.all_gather_into_tensor(recv, send, group=group)
+    full.copy_(recv[:n])
 
 
 def halo_exchange(band, radius, rank, world, dist, group=None):
@@ -88,19 +97,48 @@ class _DevArray:
 
 
 class PositionExchange:
-    """All-gather of particle positions between steps, in place on the renderer's device arrays."""
+    """All-gather of particle positions between steps, in place on the renderer's device arrays.
 
-    def __init__(self, renderer, n, first, count, torch):
+    One collective per step carries x and y together: every rank sends [x of its range | y of its range] (padded to
+    the longest range) and unpacks the gathered blocks into both position arrays. Everything is queued on the
+    renderer's own HIP stream (wrapped as a torch ExternalStream): the pack waits for the step kernel in stream order,
+    the collective is ordered against that stream by the process group's own events, and the next step's kernel waits
+    for the unpack - no host synchronisation between steps. finish() waits for the last exchange."""
+
+    def __init__(self, renderer, n, first, count, torch, group=None):
         import torch.distributed as dist
-        self.r, self.n, self.torch, self.dist = renderer, n, torch, dist
-        world = dist.get_world_size()
-        self.ranges = [particle_range(n, k, world) for k in range(world)]
-        assert self.ranges[dist.get_rank()] == (first, count)
+        self.r, self.n, self.torch, self.dist, self.group = renderer, n, torch, dist, group
+        self.world = dist.get_world_size(group)
+        self.ranges = [particle_range(n, k, self.world) for k in range(self.world)]
+        assert self.ranges[dist.get_rank(group)] == (first, count)
+        self.first, self.count = first, count
+        self.per = max(c for _, c in self.ranges)
+        # gloo (CPU rehearsals of the control flow only) moves host tensors: that path waits for the step, stages
+        # through host memory and is not meant to be fast
+        self.host = dist.get_backend(group) == "gloo"
+        self.stream = torch.cuda.ExternalStream(renderer.stream_ptr())
+        with torch.cuda.stream(self.stream):
+            self.send = torch.zeros(2 * self.per, dtype=torch.float32, device="cuda")
+            self.recv = torch.empty(self.world * 2 * self.per, dtype=torch.float32, device="cuda")
 
     def exchange(self):
-        self.r.sync()                                  # the step ran on the renderer's own stream
+        torch = self.torch
         x_ptr, y_ptr = self.r.particles_positions()    # buffers the next step will read
-        for ptr in (x_ptr, y_ptr):
-            t = self.torch.as_tensor(_DevArray(ptr, self.n), device="cuda")
-            gather_ranges(t, self.ranges, self.dist)
-        self.torch.cuda.current_stream().synchronize()
+        with torch.cuda.stream(self.stream):
+            x = torch.as_tensor(_DevArray(x_ptr, self.n), device="cuda")
+            y = torch.as_tensor(_DevArray(y_ptr, self.n), device="cuda")
+            f, c, per = self.first, self.count, self.per
+            self.send[:c].copy_(x[f:f + c])
+            self.send[per:per + c].copy_(y[f:f + c])
+            if self.host:
+                send, recv = self.send.cpu(), torch.empty(self.recv.shape, dtype=torch.float32)
+                self.dist.all_gather_into_tensor(recv, send, group=self.group)
+                self.recv.copy_(recv)
+            else:
+                self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+            blocks = self.recv.view(self.world, 2, per)
+            x.copy_(blocks[:, 0, :].reshape(-1)[:self.n])
+            y.copy_(blocks[:, 1, :].reshape(-1)[:self.n])
+
+    def finish(self):
+        self.stream.synchronize()

@@ -219,6 +219,10 @@ int game_hip_reset_memory(game_hip_ctx* ctx);          /* previous-frame store :
  * run returned - as the frame the next rendered frame reads as its previous one. Synchronous. */
 int game_hip_set_memory(game_hip_ctx* ctx, const uint8_t* rgba8_frame, uint32_t row0, uint32_t rows);
 int game_hip_sync(game_hip_ctx* ctx);                  /* wait for the context's stream */
+/* The context's HIP stream (a hipStream_t): every launch and copy of the context is queued on it, so work a caller
+ * queues on the same stream - a collective over the particle arrays, a consumer of a ring slot - is ordered against
+ * the context's kernels without a host synchronisation. */
+void* game_hip_stream(game_hip_ctx* ctx);
 void* game_hip_frame_ptr(game_hip_ctx* ctx, uint32_t slot);   /* device pointer of a ring slot */
 uint32_t game_hip_ring_frames(const game_hip_ctx* ctx);
 /* Device time of the kernels of the last render call, from HIP events recorded on the context's
@@ -230,8 +234,15 @@ int game_hip_last_kernel_ms(game_hip_ctx* ctx, float* ms, uint32_t* launches);
  * still works and waits for that call.) */
 int game_hip_timing_begin(game_hip_ctx* ctx);
 int game_hip_timing_end(game_hip_ctx* ctx, float* total_ms, uint32_t* launches);
-/* Source text of the generated kernel (for inspection and tests). */
+/* Source text of the generated kernel (for inspection and tests), and of the device-function header it includes
+ * (the two together are everything hiprtc compiles; a hash of both identifies a kernel build). */
 const char* game_hip_kernel_source(const game_hip_ctx* ctx);
+const char* game_hip_gravity_source(const game_hip_ctx* ctx);   /* "" without a gravity block */
+const char* game_hip_device_header_source(void);
+/* Host milliseconds game_hip_create spent (a) in hiprtc for this context's kernels - 0 when the process had already
+ * compiled the same source - and (b) building the per-device lattice tables - 0 when the device already had them.
+ * The browser's counterpart is shader compilation inside GameRendererGL.init (runtime/helpers.rs:148-183). */
+int game_hip_setup_ms(const game_hip_ctx* ctx, float* compile_ms, float* tables_ms);
 /* Compile the generated kernel for gfx950 without touching a device (build-time check). */
 int game_hip_compile_only(const game_ir* ir, size_t* code_bytes);
 int game_hip_compile_only_ex(const game_ir* ir, uint32_t flags, size_t* code_bytes);
