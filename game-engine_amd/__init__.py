@@ -87,6 +87,7 @@ def _load():
         "game_hip_set_ring": (c.c_int, [vp, u32]),
         "game_hip_render": (c.c_int, [vp, vp, u32, vp]),
         "game_hip_render_band": (c.c_int, [vp, vp, u32, u32, u32, vp]),
+        "game_hip_render_into": (c.c_int, [vp, vp, u32, vp]),
         "game_hip_host_alloc": (vp, [sz]),
         "game_hip_host_free": (None, [vp]),
         "game_hip_reset_memory": (c.c_int, [vp]),
@@ -429,6 +430,11 @@ class Renderer:
             out = pinned_array(shape) if pinned else np.empty(shape, dtype=np.uint8)
         _check(lib.game_hip_render(self._h, rows.ctypes.data, rows.shape[0], None if out is None else out.ctypes.data))
         return out
+
+    def render_into(self, rows, dev_ptr):
+        """Allocation-free variant: frames go to the caller's device buffer (len(rows) * h * w * 4 bytes at dev_ptr)."""
+        rows = self._rows(rows)
+        _check(lib.game_hip_render_into(self._h, rows.ctypes.data, rows.shape[0], dev_ptr))
 
     def render_band(self, rows, row0, nrows, readback=True):
         rows = self._rows(rows)

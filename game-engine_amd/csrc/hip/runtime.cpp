@@ -6,12 +6,14 @@
 // and GameGravitySim (game-compiler/src/codegen/gravity.rs:123-191).
 #include "../front/capi_internal.hpp"
 #include "codegen.hpp"
+#include "scratch.hpp"
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
@@ -67,6 +69,12 @@ struct game_hip_ctx {
     int cur = 0;
     float sim_time = 0.0f;
     float compile_ms = 0.0f, tables_ms = 0.0f;   // host time game_hip_create spent in hiprtc / building lattice tables
+    // game_hip_render_into: this device's static scratch array (not owned), a page-locked staging buffer of the same
+    // size made at creation, and the event that says the last copy out of the staging buffer has finished
+    float* scratch = nullptr;
+    float* stage_host = nullptr;
+    hipEvent_t ev_stage = nullptr;
+    bool stage_busy = false;
 };
 
 namespace {
@@ -501,6 +509,9 @@ int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int d
     if ((e = hipEventCreate(&c->ev_own0)) != hipSuccess) return fail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev_own1)) != hipSuccess) return fail("hipEventCreate", e);
     c->ev0 = c->ev_own0; c->ev1 = c->ev_own1;
+    if ((e = hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipHostMalloc((void**)&c->stage_host, GAME_HIP_SCRATCH_BYTES, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
+    { void* sp = nullptr; rc = scratch_for_current_device(&sp); if (rc) { game_hip_destroy(c); return rc; } c->scratch = (float*)sp; }
     rc = ensure_ring(c, c->ir.uses_memory ? 2u : 4u);
     if (rc) { game_hip_destroy(c); return rc; }
     t0 = now_ms();
@@ -550,6 +561,8 @@ void game_hip_destroy(game_hip_ctx* c)
     }
     if (c->vx) (void)hipFree(c->vx);
     if (c->vy) (void)hipFree(c->vy);
+    if (c->stage_host) (void)hipHostFree(c->stage_host);
+    if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
     if (c->ev_own0) (void)hipEventDestroy(c->ev_own0);
     if (c->ev_own1) (void)hipEventDestroy(c->ev_own1);
     for (auto& p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -580,6 +593,54 @@ int game_hip_render_band(game_hip_ctx* c, const float* uniforms, uint32_t nframe
 {
     if (!c) return set_error(GAME_E_ARGUMENT, "game_hip_render_band: null context");
     return render_impl(c, uniforms, nframes, row0, rows, rgba8_host);
+}
+
+int game_hip_render_into(game_hip_ctx* c, const float* uniforms, uint32_t nframes, void* rgba8_dev)
+{
+    if (!c || !uniforms || !rgba8_dev) return set_error(GAME_E_ARGUMENT, "game_hip_render_into: null argument");
+    if (nframes == 0) return GAME_OK;
+    const size_t row_bytes = (size_t)c->ustride * 4;
+    if (nframes > 65535u || (size_t)nframes * row_bytes > GAME_HIP_SCRATCH_BYTES)
+        return set_error(GAME_E_ARGUMENT, "game_hip_render_into: " + std::to_string(nframes) + " frames of " + std::to_string(row_bytes) +
+                                              " bytes of uniforms exceed the static scratch (" + std::to_string(GAME_HIP_SCRATCH_BYTES) +
+                                              " bytes, at most " + std::to_string(std::min<size_t>(65535u, GAME_HIP_SCRATCH_BYTES / row_bytes)) +
+                                              " frames per call for this cinematic)");
+    if (((uintptr_t)rgba8_dev & 15u) != 0) return set_error(GAME_E_ARGUMENT, "game_hip_render_into: the output must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(c->device));
+    // the staging buffer is free again once the previous call's copy out of it has run
+    if (c->stage_busy) { HIP_TRY(hipEventSynchronize(c->ev_stage)); c->stage_busy = false; }
+    build_rows(c, uniforms, nframes, c->stage_host);
+    HIP_TRY(hipMemcpyAsync(c->scratch, c->stage_host, (size_t)nframes * row_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_stage, c->stream));
+    c->stage_busy = true;
+    uint32_t* out = (uint32_t*)rgba8_dev;
+    const size_t frame_px = (size_t)c->w * c->h;
+    const bool timed = !c->timing;   // the context's own event pair; a timing section's per-call pairs may need creating
+    c->last_launches = 0;
+    if (timed) { c->own_recorded = false; HIP_TRY(hipEventRecord(c->ev_own0, c->stream)); }
+    if (c->ir.uses_memory) {
+        // frame-serial: frame 0 continues from the context's feedback state, frame k reads frame k - 1 of the output
+        const uint32_t* prev = c->last_slot >= 0 && c->frames ? c->frames + (size_t)c->last_slot * frame_px : nullptr;
+        for (uint32_t f = 0; f < nframes; ++f) {
+            int rc = launch_frames_into(c, out, nframes, c->scratch, f, 1, f, prev, 0, c->h);
+            if (rc) return rc;
+            ++c->last_launches;
+            prev = out + (size_t)f * frame_px;
+        }
+        if (c->frames && c->ring) {   // the last frame becomes the state the next call (of either kind) continues from
+            const uint32_t slot = c->next_slot;
+            HIP_TRY(hipMemcpyAsync(c->frames + (size_t)slot * frame_px, out + (size_t)(nframes - 1) * frame_px, frame_px * 4,
+                                   hipMemcpyDeviceToDevice, c->stream));
+            c->last_slot = (int)slot;
+            c->next_slot = (slot + 1u) % c->ring;
+        }
+    } else {
+        int rc = launch_frames_into(c, out, nframes, c->scratch, 0, nframes, 0, nullptr, 0, c->h);
+        if (rc) return rc;
+        ++c->last_launches;
+    }
+    if (timed) { HIP_TRY(hipEventRecord(c->ev_own1, c->stream)); c->own_recorded = true; }
+    return GAME_OK;
 }
 
 int game_hip_reset_memory(game_hip_ctx* c)

@@ -208,6 +208,19 @@ int game_hip_render(game_hip_ctx* ctx, const float* uniforms, uint32_t nframes, 
  * not touched. rgba8_host, when non-NULL, receives only the band (nframes * rows * w * 4). */
 int game_hip_render_band(game_hip_ctx* ctx, const float* uniforms, uint32_t nframes, uint32_t row0,
                          uint32_t rows, uint8_t* rgba8_host);
+/* The same frames as game_hip_render, without any allocation. This entry point has NO counterpart in the reference: it
+ * is for callers that cannot allocate device memory while they render - code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc. The caller passes the input rows (host) and the output (rgba8_dev: DEVICE
+ * memory, 16-byte aligned, nframes * w * h * 4 bytes, frame k at offset k * w * h * 4, top row first); the staging copy
+ * of the uniform rows, which the other render calls keep in a buffer of their own, lives in a file-scope device array
+ * of GAME_HIP_SCRATCH_BYTES = 262144 bytes that every GPU the library runs on holds until the process ends. The call
+ * makes no hipMalloc / hipFree / hipHostMalloc / event creation; everything it needs was made by game_hip_create. It
+ * returns when the work is queued on the context's stream (game_hip_sync waits). Limits: nframes * (frame floats + 2
+ * + derived values) * 4 <= 262144 and nframes <= 65535, GAME_E_ARGUMENT beyond. Memory cinematics continue from, and
+ * update, the context's feedback state exactly as game_hip_render does. All contexts of one GPU share that GPU's array,
+ * which keeps the last call's contents: calls of this entry point that overlap on one GPU (distinct contexts driven
+ * concurrently) race on it - serialise them, or use game_hip_render. Inside a timing section the call is not timed. */
+int game_hip_render_into(game_hip_ctx* ctx, const float* uniforms, uint32_t nframes, void* rgba8_dev);
 /* Page-locked host memory for the rgba8_host argument: frames then leave the GPU by DMA at PCIe rate
  * instead of through the staged copy a pageable buffer gets (about 4x faster on the tested host). Any host
  * pointer is accepted by the render calls; this pair is a convenience around hipHostMalloc / hipHostFree. */
