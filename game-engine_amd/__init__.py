@@ -129,10 +129,11 @@ lib, EXPORTED_SYMBOLS = _load()
 SEMANTICS = {"glsl": 0, "wgsl": 1}   # GAME_HIP_SEMANTICS_WGSL
 ANIMATE_ARGS = 2                     # GAME_HIP_ANIMATE_ARGS
 LENS_POST = 4                        # GAME_HIP_LENS_POST
+GRAVITY_FAST = 8                     # GAME_HIP_GRAVITY_FAST
 
 
-def _flags(semantics, animate, lens_post):
-    return SEMANTICS[semantics] | (ANIMATE_ARGS if animate else 0) | (LENS_POST if lens_post else 0)
+def _flags(semantics, animate, lens_post, gravity_fast=False):
+    return SEMANTICS[semantics] | (ANIMATE_ARGS if animate else 0) | (LENS_POST if lens_post else 0) | (GRAVITY_FAST if gravity_fast else 0)
 
 
 def _check(rc):
@@ -239,11 +240,11 @@ class Cinematic:
         """Writes the generated kernel source and gfx950 code object next to `path_prefix`."""
         _check(lib.game_hip_dump_code(self._h, path_prefix.encode()))
 
-    def renderer(self, w, h, device=0, semantics="glsl", animate=False, lens_post=False):
+    def renderer(self, w, h, device=0, semantics="glsl", animate=False, lens_post=False, gravity_fast=False):
         """semantics: "glsl" = the reference's WebGL2 wording of the builtins (default), "wgsl" = its WebGPU wording.
         animate: expression-valued stage arguments take their per-frame value instead of the parameter default.
         lens_post: the `lens { post: ... }` chain runs on the composited colour (the reference ignores it)."""
-        return Renderer(self, w, h, device, semantics, animate, lens_post)
+        return Renderer(self, w, h, device, semantics, animate, lens_post, gravity_fast)
 
 
 class Program:
@@ -390,11 +391,11 @@ class Animator:
 class Renderer:
     """GPU context for one cinematic at one resolution (reference: GameRendererGL, runtime/helpers.rs:131-241)."""
 
-    def __init__(self, cinematic, w, h, device=0, semantics="glsl", animate=False, lens_post=False):
+    def __init__(self, cinematic, w, h, device=0, semantics="glsl", animate=False, lens_post=False, gravity_fast=False):
         self.cinematic = cinematic
         self.w, self.h = w, h
         h_ = ctypes.c_void_p()
-        _check(lib.game_hip_create_ex(cinematic._h, w, h, device, _flags(semantics, animate, lens_post), ctypes.byref(h_)))
+        _check(lib.game_hip_create_ex(cinematic._h, w, h, device, _flags(semantics, animate, lens_post, gravity_fast), ctypes.byref(h_)))
         self._h = h_
 
     def close(self):
@@ -530,7 +531,7 @@ class Renderer:
 
 EVAL_OPS = {"fract": 0, "sin": 1, "cos": 2, "atan2": 3, "hash2": 4, "noise2": 5, "simplex2d": 6, "voronoi2d": 7,
             "exp2": 8, "log2": 9, "pow": 10, "max": 11, "min": 12, "fbm6": 13, "sqrt": 14, "div": 15,
-            "smoothstep_glow": 16, "mod": 17, "unorm8": 18, "noise2_lut": 19, "fbm6_lut": 20, "voronoi2d_lut": 21, "simplex2d_lut": 22}
+            "smoothstep_glow": 16, "mod": 17, "unorm8": 18, "noise2_lut": 19, "fbm6_lut": 20, "voronoi2d_lut": 21, "simplex2d_lut": 22, "pack_unorm8": 23}
 
 
 def device_eval(op, a, b=None):

@@ -18,6 +18,7 @@ struct KernelShape {
 
 std::string float_literal(float v);
 std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape);
-std::string generate_gravity_kernel(const Ir& ir);
+// fast: root and reciprocal of the pair distance from one v_rsq_f32 (not bit-reproducible on a CPU; within tolerance)
+std::string generate_gravity_kernel(const Ir& ir, bool fast = false);
 
 }  // namespace game

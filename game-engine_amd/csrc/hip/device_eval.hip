@@ -13,7 +13,7 @@ using namespace game;
 namespace {
 
 enum EvalOp { EV_FRACT = 0, EV_SIN, EV_COS, EV_ATAN2, EV_HASH2, EV_NOISE2, EV_SIMPLEX, EV_VORONOI, EV_EXP2, EV_LOG2, EV_POW,
-              EV_MAX, EV_MIN, EV_FBM6, EV_SQRT, EV_DIV, EV_SMOOTHSTEP_GLOW, EV_MOD, EV_UNORM8, EV_NOISE2_LUT, EV_FBM6_LUT, EV_VORONOI_LUT, EV_SIMPLEX_LUT, EV_COUNT };
+              EV_MAX, EV_MIN, EV_FBM6, EV_SQRT, EV_DIV, EV_SMOOTHSTEP_GLOW, EV_MOD, EV_UNORM8, EV_NOISE2_LUT, EV_FBM6_LUT, EV_VORONOI_LUT, EV_SIMPLEX_LUT, EV_PACK_UNORM8, EV_COUNT };
 
 // Fills the lattice-hash table: entry (row iy + 512, column ix + 512) = {hash2(ix, iy), hash2(ix, iy + 1)}.
 __global__ void hash_lut_fill(float* __restrict__ table)
@@ -77,6 +77,7 @@ __global__ void eval_kernel(int op, uint32_t n, const float* __restrict__ a, con
     case EV_FBM6_LUT: r = gd_fbm2(x, y, 6, 0.5f, 2.0f, lut); break;
     case EV_VORONOI_LUT: r = gd_voronoi2d_lut(x, y, 5.0f, lut); break;
     case EV_SIMPLEX_LUT: r = gd_simplex2d(x, y, lut); break;
+    case EV_PACK_UNORM8: r = (float)(gd_pack_rgba8(x, 0.0f, 0.0f, 0.0f) & 0xffu); break;
     default: break;
     }
     out[i] = r;

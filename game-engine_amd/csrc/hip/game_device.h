@@ -493,7 +493,8 @@ GD float gd_voronoi2d_lut(float px, float py, float scale, const float* __restri
 GD float gd_apply_glow(float d, float intensity)   // glsl.rs:102-107
 {
     float core = gd_smoothstep(0.005f, -0.005f, d);
-    float halo = intensity / __builtin_fmaf(gd_max(d, 0.0f) * gd_max(d, 0.0f) * intensity * intensity, 16.0f, 1.0f);
+    // the halo quotient is one correctly rounded reciprocal and one multiply (the denominator is >= 1 or not finite)
+    float halo = intensity * gd_rcp(__builtin_fmaf(gd_max(d, 0.0f) * gd_max(d, 0.0f) * intensity * intensity, 16.0f, 1.0f));
     return core + halo;
 }
 
@@ -505,12 +506,22 @@ struct GdPix {
     float sdf;             // `sdf_result`
     float r, g, b, a;      // `color_result`
     float uvx, uvy;        // `uv`
+    float uvlen, uvinv;    // length(uv) and 1 / length(uv), set by gd_uv_length for the stages that read them
     float time;            // fract(u_time / 120) * 120
     float bass, mid, treble;
     const float* lut;      // lattice-hash table (uniform; may be null)
     const float* vlut;     // voronoi feature-point table (uniform; may be null)
     const float* slut;     // simplex corner table (uniform; may be null)
 };
+
+// length(uv) and its reciprocal, both correctly rounded, once per pixel: vignette and chromatic (and their WebGPU
+// wordings) all start from length(uv), and normalize(uv) is uv * (1 / length(uv)). uv = 0 gives 0 and +inf.
+GD void gd_uv_length(GdPix& s)
+{
+    const float d2 = __builtin_fmaf(s.uvx, s.uvx, s.uvy * s.uvy);
+    if (gd_wave_all(d2 >= 0x1p-100f && d2 < __builtin_inff())) gd_sqrt_rcp_core(d2, s.uvlen, s.uvinv);
+    else { s.uvlen = __builtin_sqrtf(d2); s.uvinv = 1.0f / s.uvlen; }
+}
 
 // SDF generators: Position -> Sdf
 GD void gb_circle(GdPix& s, float radius) { s.sdf = gd_length2(s.px, s.py) - radius; }                 // glsl.rs:265-268
@@ -658,14 +669,13 @@ GD void gb_grain(GdPix& s, float amount)                                        
 }
 GD void gb_vignette(GdPix& s, float strength, float radius)                                             // :458-464
 {
-    float dist = gd_length2(s.uvx, s.uvy);
+    float dist = s.uvlen;
     float f = 1.0f - gd_smoothstep(radius, radius + strength, dist);
     s.r = s.r * f; s.g = s.g * f; s.b = s.b * f;
 }
 GD void gb_chromatic(GdPix& s, float offset)                                                            // :465-472
 {
-    float len = gd_length2(s.uvx, s.uvy);
-    float dirx = s.uvx / len * offset;
+    float dirx = s.uvx * s.uvinv * offset;   // normalize(uv).x * offset
     s.r = s.r * (1.0f + dirx);
     s.b = s.b * (1.0f - dirx);
 }
@@ -816,14 +826,14 @@ GD void gw_concentric_waves(GdPix& s, float amplitude, float width, float freque
 GD void gw_threshold(GdPix& s, float cutoff) { s.sdf = gw_step(cutoff, s.sdf); }                        // wgsl.rs:501-504
 GD void gw_vignette(GdPix& s, float strength, float radius)                                             // wgsl.rs:392-398
 {
-    float d = gd_length2(s.uvx, s.uvy);
+    float d = s.uvlen;
     float vig = gd_smoothstep(radius + 0.3f, radius - 0.2f, d);
     float f = gd_mix(1.0f, vig, strength);
     s.r = s.r * f; s.g = s.g * f; s.b = s.b * f;
 }
 GD void gw_chromatic(GdPix& s, float offset)                                                            // wgsl.rs:399-408
 {
-    float d = gd_length2(s.uvx, s.uvy) * offset;
+    float d = s.uvlen * offset;
     s.r = s.r + d * 0.5f;
     s.b = s.b - d * 0.5f;
 }
@@ -889,16 +899,8 @@ GD void gw_spectrum(GdPix& s, float bass, float mid, float treble)              
     s.a = 1.0f;
 }
 
-// b / 255 for b in 0..255, correctly rounded, without the division sequence: 1/255 split into a float
-// and the float nearest to what is left (hi + lo = 1/255 to 2^-57), b * lo rounded once and folded into
-// b * hi by one fma. The result is the correctly rounded quotient for every one of the 256 inputs
-// (checked exhaustively by the tests).
-GD float gd_unorm8_to_float(gd_u32 b)
-{
-    const float hi = 0x1.010102p-8f, lo = -0x1.fdfdfep-33f;
-    float u = (float)b;
-    return __builtin_fmaf(u, hi, u * lo);
-}
+// RGBA8 texel -> float: the byte times the float nearest to 1 / 255 (255 maps to exactly 1).
+GD float gd_unorm8_to_float(gd_u32 b) { return (float)b * 0x1.010102p-8f; }
 // Memory feedback (game-compiler/src/codegen/memory.rs:38-45): mix with the previous frame's
 // RGBA8 texel at the same pixel.
 GD void gb_memory_mix(GdPix& s, gd_u32 prev, float decay)
@@ -909,9 +911,13 @@ GD void gb_memory_mix(GdPix& s, gd_u32 prev, float decay)
     s.b = gd_mix(s.b, pb, decay); s.a = gd_mix(s.a, pa, decay);
 }
 
-// Framebuffer write: RGBA8 unorm, round(clamp(c, 0, 1) * 255), R in the low byte.
-GD gd_u32 gd_unorm8(float c) { return (gd_u32)__builtin_fmaf(gd_min(gd_max(c, 0.0f), 1.0f), 255.0f, 0.5f); }
+// Framebuffer write: RGBA8 unorm, c * 255 rounded to the nearest integer (ties to even) and saturated to [0, 255],
+// NaN -> 0, R in the low byte. v_cvt_pk_u8_f32 does the rounding, the saturation and the byte insert in one instruction
+// (checked against this formula over all 2^32 inputs).
 GD gd_u32 gd_pack_rgba8(float r, float g, float b, float a)
 {
-    return gd_unorm8(r) | (gd_unorm8(g) << 8) | (gd_unorm8(b) << 16) | (gd_unorm8(a) << 24);
+    gd_u32 q = __builtin_amdgcn_cvt_pk_u8_f32(r * 255.0f, 0u, 0u);
+    q = __builtin_amdgcn_cvt_pk_u8_f32(g * 255.0f, 1u, q);
+    q = __builtin_amdgcn_cvt_pk_u8_f32(b * 255.0f, 2u, q);
+    return __builtin_amdgcn_cvt_pk_u8_f32(a * 255.0f, 3u, q);
 }

@@ -59,7 +59,9 @@ struct game_hip_ctx {
     uint32_t last_launches = 0;
     // particles
     hipModule_t gmod = nullptr;
-    hipFunction_t gfn = nullptr;
+    hipFunction_t gfn = nullptr;      // one particle per lane
+    hipFunction_t gfn2 = nullptr;     // two particles per lane (tuning hook)
+    bool gravity_fast = false;
     std::string gsource;
     uint32_t n = 0;
     float* px[2] = {nullptr, nullptr};
@@ -477,7 +479,8 @@ int game_hip_create(const game_ir* ir, uint32_t width, uint32_t height, int devi
 int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int device, uint32_t flags, game_hip_ctx** out)
 {
     if (!ir || !out) return set_error(GAME_E_ARGUMENT, "game_hip_create: null argument");
-    if (flags & ~(uint32_t)(GAME_HIP_SEMANTICS_WGSL | GAME_HIP_ANIMATE_ARGS | GAME_HIP_LENS_POST)) return set_error(GAME_E_ARGUMENT, "game_hip_create_ex: unknown flag");
+    if (flags & ~(uint32_t)(GAME_HIP_SEMANTICS_WGSL | GAME_HIP_ANIMATE_ARGS | GAME_HIP_LENS_POST | GAME_HIP_GRAVITY_FAST))
+        return set_error(GAME_E_ARGUMENT, "game_hip_create_ex: unknown flag");
     *out = nullptr;
     if (width == 0 || height == 0 || width > 65536 || height > 65535)
         return set_error(GAME_E_ARGUMENT, "game_hip_create: width must be in 1..65536 and height in 1..65535");
@@ -536,13 +539,15 @@ int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int d
     }
     c->tables_ms = (float)(now_ms() - t0);
     if (c->ir.gravity.present) {
-        c->gsource = generate_gravity_kernel(c->ir);
+        c->gravity_fast = (flags & GAME_HIP_GRAVITY_FAST) != 0;
+        c->gsource = generate_gravity_kernel(c->ir, c->gravity_fast);
         t0 = now_ms();
         rc = compile_hip(c->gsource, "game_gravity.hip", code);
         c->compile_ms += (float)(now_ms() - t0);
         if (rc) { game_hip_destroy(c); return rc; }
         if ((e = hipModuleLoadData(&c->gmod, code.data())) != hipSuccess) return fail("hipModuleLoadData(gravity)", e);
         if ((e = hipModuleGetFunction(&c->gfn, c->gmod, "game_gravity")) != hipSuccess) return fail("hipModuleGetFunction(gravity)", e);
+        if ((e = hipModuleGetFunction(&c->gfn2, c->gmod, "game_gravity_p2")) != hipSuccess) return fail("hipModuleGetFunction(gravity)", e);
     }
     *out = c;
     return GAME_OK;
@@ -842,6 +847,15 @@ int game_hip_particles_step(game_hip_ctx* c, float dt, uint32_t steps, uint32_t 
     if (count < c->n && steps > 1)
         return set_error(GAME_E_ARGUMENT, "game_hip_particles_step: a partial range advances one step per call (exchange positions between steps)");
     HIP_TRY(hipSetDevice(c->device));
+    // Particles per lane: one. The two-particle build halves the LDS reads per pair, but the loop is bound by VALU
+    // issue and it measured no faster; it stays selectable for measurements.
+    uint32_t ppl = 1u;
+    if (const char* e = getenv("GAME_HIP_GRAV_PPL")) {   // tuning hook
+        int v = atoi(e);
+        if (v == 1 || v == 2) ppl = (uint32_t)v;
+    }
+    hipFunction_t gfn = ppl == 2 ? c->gfn2 : c->gfn;
+    const uint32_t span = 256u * ppl;
     c->last_launches = 0;
     { int erc = begin_call_events(c); if (erc) return erc; }
     CallEvents events(c);
@@ -855,7 +869,7 @@ int game_hip_particles_step(game_hip_ctx* c, float dt, uint32_t steps, uint32_t 
         P.n = c->n; P.first = first; P.count = count; P.pad = 0;
         P.dt = dt; P.time = c->sim_time;
         void* args[] = {&P};
-        HIP_TRY(hipModuleLaunchKernel(c->gfn, (count + 255u) / 256u, 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+        HIP_TRY(hipModuleLaunchKernel(gfn, (count + span - 1u) / span, 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
         ++c->last_launches;
         c->cur = 1 - c->cur;
     }

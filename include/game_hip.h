@@ -187,7 +187,11 @@ enum {
     /* `lens { post: bloom(0.4, 1.5) | grain(0.015) }` is parsed by the reference (parser.rs:1197-1234) and then ignored
      * by both of its emitters. With this flag the Color -> Color builtins of the chain run, in order, on the colour
      * composited from the layers, before the frame is stored (and so before it becomes the next frame's memory). */
-    GAME_HIP_LENS_POST = 4u
+    GAME_HIP_LENS_POST = 4u,
+    /* Gravity step with the pair distance and its reciprocal taken from one hardware reciprocal-square-root
+     * (about 1 ulp each) instead of the correctly rounded root and reciprocal of the default build. Not bit-reproducible
+     * on a CPU; positions stay within the stated tolerance of the default build (1e-4 relative after 100 steps). */
+    GAME_HIP_GRAVITY_FAST = 8u
 };
 int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int device, uint32_t flags,
                        game_hip_ctx** out);
@@ -284,8 +288,9 @@ int game_hip_particles_set_time(game_hip_ctx* ctx, float sim_time);
  * compare them bit-for-bit with a CPU restatement. op: 0 fract, 1 sin, 2 cos, 3 atan2(a,b),
  * 4 hash2(a,b), 5 noise2(a,b), 6 simplex2d(a,b), 7 voronoi2d(a,b,5), 8 exp2, 9 log2, 10 pow(a,b),
  * 11 max(a,b), 12 min(a,b), 13 fbm2(a,b,6,.5,2), 14 sqrt, 15 a/b, 16 smoothstep(.005,-.005,a),
- * 17 mod(a,b), 18 unorm8 -> float of (uint)a, 19 / 20 noise2 / fbm2 through the lattice-hash table,
- * 21 voronoi2d(a,b,5) through the feature-point table, 22 simplex2d(a,b) through the corner table.
+ * 17 mod(a,b), 18 texel fetch: float of the byte (uint)a, 19 / 20 noise2 / fbm2 through the lattice-hash table,
+ * 21 voronoi2d(a,b,5) through the feature-point table, 22 simplex2d(a,b) through the corner table, 23 the byte the
+ * framebuffer write stores for the colour value a.
  * b may be NULL for one-argument ops. */
 int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out);
 /* Exhaustive check, over all 2^32 float bit patterns, that the hardware instruction equals its

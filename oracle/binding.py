@@ -30,6 +30,8 @@ class Oracle:
         L.game_oracle_gravity.restype = c.c_int
         L.game_oracle_gravity.argtypes = [c.c_void_p, c.c_size_t, c.c_uint32, c.c_void_p, c.c_float, c.c_uint32,
                                           c.POINTER(c.c_float), c.c_int]
+        L.game_oracle_set_gravity_blocked.restype = None
+        L.game_oracle_set_gravity_blocked.argtypes = [c.c_int]
         L.game_oracle_seed_particles.restype = None
         L.game_oracle_seed_particles.argtypes = [c.c_uint32, c.c_uint64, c.c_void_p]
         for name, nargs in (("sin", 1), ("cos", 1), ("atan2", 2), ("fract", 1), ("hash2", 2), ("noise2", 2),
@@ -74,7 +76,9 @@ class Oracle:
         self.L.game_oracle_seed_particles(n, seed, p.ctypes.data)
         return p
 
-    def gravity(self, blob, particles, dt, steps, sim_time=0.0, threads=8):
+    def gravity(self, blob, particles, dt, steps, sim_time=0.0, threads=8, blocked=True):
+        """blocked=False forces the one-particle-at-a-time loop even for constant force laws."""
+        self.L.game_oracle_set_gravity_blocked(1 if blocked else 0)
         p = np.ascontiguousarray(particles, dtype=np.float32).copy()
         t = ctypes.c_float(sim_time)
         rc = self.L.game_oracle_gravity(blob, len(blob), p.shape[0], p.ctypes.data, dt, steps, ctypes.byref(t), threads)

@@ -19,6 +19,7 @@
  * Input is the flat IR blob produced by the front end (layout in include/game_hip.h).
  */
 #include "gm_math.h"
+#include <immintrin.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <stdio.h>
@@ -187,7 +188,7 @@ static float voronoi2d(float px, float py, float scale)   /* glsl.rs:202-219 */
 static float apply_glow(float d, float intensity)   /* glsl.rs:102-107 */
 {
     float core = gm_smoothstep(0.005f, -0.005f, d);
-    float halo = intensity / fmaf(gm_max(d, 0.0f) * gm_max(d, 0.0f) * intensity * intensity, 16.0f, 1.0f);
+    float halo = intensity * gm_rcp(fmaf(gm_max(d, 0.0f) * gm_max(d, 0.0f) * intensity * intensity, 16.0f, 1.0f));   /* reciprocal, multiply */
     return core + halo;
 }
 
@@ -297,11 +298,13 @@ static inline float arg_value(const ir_arg* a, const frame_consts* fc, const ir_
     return a->slot == BU_TIME ? fc->time : fc->row[a->slot];
 }
 
-static inline uint32_t pack_unorm8(float c)   /* framebuffer write: round(clamp(c, 0, 1) * 255) */
+static inline uint32_t pack_unorm8(float c)   /* framebuffer write: c * 255 to the nearest integer (ties to even), saturated; NaN -> 0 */
 {
-    float t = gm_min(gm_max(c, 0.0f), 1.0f);
-    return (uint32_t)fmaf(t, 255.0f, 0.5f);
+    float t = rintf(c * 255.0f);              /* the default rounding mode is to nearest even */
+    if (!(t > 0.0f)) return 0u;
+    return t >= 255.0f ? 255u : (uint32_t)t;
 }
+static inline float unorm8_to_float(uint32_t b) { return (float)b * 0x1.010102p-8f; }   /* texel fetch: byte times RN(1 / 255) */
 
 /* ── WGSL-semantics variants (game-compiler/src/codegen/wgsl.rs) ───────────────────────── */
 static inline float w_rem(float x, float y) { return x - y * truncf(x * gm_rcp(y)); }   /* WGSL `%` on f32 */
@@ -636,7 +639,7 @@ static void shade_pixel(const ir_view* ir, const frame_consts* fc, float uvx, fl
             }
             case B_CHROMATIC: {                                                                    /* :465-472 */
                 float len = gm_length2(uvx, uvy);
-                float dirx = uvx / len * a0;                                                       /* normalize(uv) * offset */
+                float dirx = uvx * gm_rcp(len) * a0;                                               /* normalize(uv) * offset: reciprocal, multiply */
                 float r = cr, b = cb;
                 cr = r * (1.0f + dirx);
                 cb = b * (1.0f - dirx);
@@ -690,8 +693,8 @@ static void shade_pixel(const ir_view* ir, const frame_consts* fc, float uvx, fl
             continue;
         }
         if (L->has_memory) {               /* memory.rs:38-45 */
-            float pr = (float)(prev & 0xffu) / 255.0f, pg = (float)((prev >> 8) & 0xffu) / 255.0f;
-            float pb = (float)((prev >> 16) & 0xffu) / 255.0f, pa = (float)(prev >> 24) / 255.0f;
+            float pr = unorm8_to_float(prev & 0xffu), pg = unorm8_to_float((prev >> 8) & 0xffu);
+            float pb = unorm8_to_float((prev >> 16) & 0xffu), pa = unorm8_to_float(prev >> 24);
             cr = gm_mix(cr, pr, L->decay); cg = gm_mix(cg, pg, L->decay);
             cb = gm_mix(cb, pb, L->decay); ca = gm_mix(ca, pa, L->decay);
         }
@@ -840,7 +843,67 @@ static void gravity_range(const grav_job* J)
         J->out[4 * idx] = px; J->out[4 * idx + 1] = py; J->out[4 * idx + 2] = vx; J->out[4 * idx + 3] = vy;
     }
 }
-static void* gravity_thread(void* p) { gravity_range((const grav_job*)p); return NULL; }
+/* The same loop for a force law that is one constant (the default rule 1.0), eight particles side by side: each of
+ * them walks j in the same order through the same correctly rounded operations (sqrtf, 1 / x, fmaf), so every
+ * particle gets the bits gravity_range gives it; written with AVX2 / FMA vector operations, each of which is the
+ * IEEE operation of its scalar counterpart in every lane.
+ * max(d, 0.001) is written as a select: a NaN distance yields 0.001 as gm_max does, and d is never negative. */
+#define GRAV_BLOCK 8
+static void gravity_range_const(const grav_job* J, float f)
+{
+    const ir_view* ir = J->ir;
+    const __m256 vf = _mm256_set1_ps(f), vmin = _mm256_set1_ps(0.001f), one = _mm256_set1_ps(1.0f);
+    for (uint32_t i0 = J->begin; i0 < J->end; i0 += GRAV_BLOCK) {
+        uint32_t id[GRAV_BLOCK];
+        float sx[GRAV_BLOCK], sy[GRAV_BLOCK], fx[GRAV_BLOCK], fy[GRAV_BLOCK];
+        const uint32_t m = J->end - i0 < GRAV_BLOCK ? J->end - i0 : GRAV_BLOCK;
+        for (uint32_t k = 0; k < GRAV_BLOCK; k++) {
+            id[k] = k < m ? i0 + k : i0;          /* lanes past the range repeat particle i0; their sums are dropped */
+            sx[k] = J->in[4 * id[k]]; sy[k] = J->in[4 * id[k] + 1];
+        }
+        const __m256 vsx = _mm256_loadu_ps(sx), vsy = _mm256_loadu_ps(sy);
+        const __m256i vid = _mm256_loadu_si256((const __m256i*)id);
+        __m256 vfx = _mm256_setzero_ps(), vfy = _mm256_setzero_ps();
+        for (uint32_t j = 0; j < J->n; j++) {
+            const __m256 dx = _mm256_sub_ps(_mm256_set1_ps(J->in[4 * j]), vsx), dy = _mm256_sub_ps(_mm256_set1_ps(J->in[4 * j + 1]), vsy);
+            const __m256 d = _mm256_sqrt_ps(_mm256_fmadd_ps(dx, dx, _mm256_mul_ps(dy, dy)));      /* sqrtf(fmaf(dx, dx, dy * dy)) */
+            const __m256 dist = _mm256_blendv_ps(vmin, d, _mm256_cmp_ps(d, vmin, _CMP_GT_OQ));       /* d > 0.001f ? d : 0.001f */
+            const __m256 inv = _mm256_div_ps(one, dist);
+            const __m256 nx = _mm256_fmadd_ps(_mm256_mul_ps(dx, inv), vf, vfx), ny = _mm256_fmadd_ps(_mm256_mul_ps(dy, inv), vf, vfy);
+            const __m256 self = _mm256_castsi256_ps(_mm256_cmpeq_epi32(vid, _mm256_set1_epi32((int)j)));
+            vfx = _mm256_blendv_ps(nx, vfx, self);                                                /* j == idx: the pair is skipped */
+            vfy = _mm256_blendv_ps(ny, vfy, self);
+        }
+        _mm256_storeu_ps(fx, vfx); _mm256_storeu_ps(fy, vfy);
+        for (uint32_t k = 0; k < m; k++) {
+            uint32_t idx = i0 + k;
+            float vx = J->in[4 * idx + 2] * ir->h->damping + fx[k] * J->dt;
+            float vy = J->in[4 * idx + 3] * ir->h->damping + fy[k] * J->dt;
+            float px = sx[k] + vx * J->dt, py = sy[k] + vy * J->dt;
+            if (ir->h->bounds == 0) {
+                if (px < -1.0f) { px = -1.0f; vx = -vx; }
+                if (px > 1.0f) { px = 1.0f; vx = -vx; }
+                if (py < -1.0f) { py = -1.0f; vy = -vy; }
+                if (py > 1.0f) { py = 1.0f; vy = -vy; }
+            } else if (ir->h->bounds == 1) {
+                px = gm_fract((px + 1.0f) * 0.5f) * 2.0f - 1.0f;
+                py = gm_fract((py + 1.0f) * 0.5f) * 2.0f - 1.0f;
+            }
+            J->out[4 * idx] = px; J->out[4 * idx + 1] = py; J->out[4 * idx + 2] = vx; J->out[4 * idx + 3] = vy;
+        }
+    }
+}
+static int g_gravity_blocked = 1;
+/* 0: always the one-particle-at-a-time loop (tests compare the two). */
+void game_oracle_set_gravity_blocked(int on) { g_gravity_blocked = on; }
+static void* gravity_thread(void* p)
+{
+    const grav_job* J = (const grav_job*)p;
+    const ir_view* ir = J->ir;
+    if (g_gravity_blocked && ir->h->n_law == 1 && ir->law[0].op == LAW_NUM) gravity_range_const(J, ir->law[0].val);
+    else gravity_range(J);
+    return NULL;
+}
 
 /* Advances `steps` steps of dt. particles: n x {pos.x, pos.y, vel.x, vel.y}, updated in place.
  * *sim_time is the dispatch clock (`_time += dt` before each step, gravity.rs:158). */
@@ -864,7 +927,7 @@ int game_oracle_gravity(const void* blob, size_t blob_len, uint32_t n, float* pa
             jobs[t].begin = (uint32_t)((uint64_t)n * (uint32_t)t / (uint32_t)nthreads);
             jobs[t].end = (uint32_t)((uint64_t)n * (uint32_t)(t + 1) / (uint32_t)nthreads);
         }
-        if (nthreads == 1) gravity_range(&jobs[0]);
+        if (nthreads == 1) gravity_thread(&jobs[0]);
         else {
             for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, gravity_thread, &jobs[t]);
             for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);

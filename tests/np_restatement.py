@@ -86,7 +86,7 @@ def apply_glow(d, intensity):  # glsl.rs:102-107
     i = F(intensity)
     core = smoothstep(0.005, -0.005, d)
     md = np.maximum(d, F(0.0))
-    halo = i / fma(md * md * i * i, F(16.0), F(1.0))
+    halo = i * (F(1.0) / fma(md * md * i * i, F(16.0), F(1.0)))   # one reciprocal, one multiply
     return core + halo
 
 
@@ -102,9 +102,9 @@ def pixel_grid(w, h):
 
 def pack(r, g, b, a):
     def u8(c):
-        c = np.where(np.isnan(c), F(0.0), c)
-        t = np.minimum(np.maximum(c, F(0.0)), F(1.0))
-        return fma(t, F(255.0), F(0.5)).astype(np.uint32).astype(np.uint8)
+        t = np.rint(c * F(255.0))                      # to the nearest integer, ties to even
+        t = np.where(np.isnan(t), F(0.0), t)
+        return np.minimum(np.maximum(t, F(0.0)), F(255.0)).astype(np.uint32).astype(np.uint8)
     return np.stack([u8(r), u8(g), u8(b), u8(np.broadcast_to(f(a), r.shape))], axis=-1)
 
 
@@ -142,7 +142,7 @@ def render_c3_no_grain(w, h, bass, mid, treble):
     add = np.maximum(lum - F(0.4), F(0.0)) * F(2.0)
     r, g, b = r + add, g + add, b + add
     ln = np.sqrt(fma(uvx, uvx, uvy * uvy))
-    dirx = uvx / ln * F(0.6)
+    dirx = uvx * (F(1.0) / ln) * F(0.6)
     r, b = r * (F(1.0) + dirx), b * (F(1.0) - dirx)
     fac = F(1.0) - smoothstep(0.8, F(0.8) + F(0.35), ln)
     return pack(r * fac, g * fac, b * fac, 1.0)
@@ -150,7 +150,7 @@ def render_c3_no_grain(w, h, bass, mid, treble):
 
 def memory_mix(cur_rgba_float, prev_rgba8, decay):
     """memory.rs:38-45 on float colours; prev is RGBA8."""
-    prev = prev_rgba8.astype(np.float32) / F(255.0)
+    prev = prev_rgba8.astype(np.float32) * F(np.float32(1.0) / np.float32(255.0))   # byte times RN(1 / 255)
     return mix(cur_rgba_float, prev, F(decay))
 
 

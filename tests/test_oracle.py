@@ -285,17 +285,20 @@ def test_seed_particles_known_answer(oracle):
     assert np.array_equal(p[:, :2].reshape(-1), np.array(vals, dtype=np.float32)) and np.all(p[:, 2:] == 0)
 
 
-def test_unorm8_fma_sequence_equals_division_for_all_bytes():
-    """The render path converts a stored byte with q = b*r, e = fma(-q, 255, b), fma(e, r, q) where
-    r = RN(1/255); the oracle divides. Both must agree for every byte."""
-    from np_restatement import fma
+def test_unorm8_texel_fetch_and_framebuffer_write_round_trip():
+    """A stored byte is fetched as b * RN(1 / 255) (255 -> exactly 1, within one ulp of b / 255 everywhere) and a colour
+    is stored as c * 255 rounded to nearest (ties to even), saturated: fetch then store returns every byte."""
+    from np_restatement import pack
     b = np.arange(256, dtype=np.float32)
     r = np.float32(1.0) / np.float32(255.0)
     assert float(r).hex() == "0x1.0101020000000p-8"
-    q = b * r
-    e = fma(-q, np.float32(255.0), b)
-    got = fma(e, r, q)
-    assert np.array_equal(got.view(np.uint32), (b / np.float32(255.0)).view(np.uint32))
+    f = b * r
+    assert f[255] == np.float32(1.0) and f[0] == 0
+    exact = b / np.float32(255.0)
+    assert np.all(np.abs(f.view(np.int32) - exact.view(np.int32)) <= 1)
+    assert np.array_equal(pack(f, f, f, 1.0)[:, 0], np.arange(256, dtype=np.uint8))
+    edge = np.array([-1.0, -0.0, 0.5 / 255, 1.5 / 255, 2.5 / 255, 0.5, 1.0, 7.0, np.inf, -np.inf, np.nan], dtype=np.float32)
+    assert pack(edge, edge, edge, 1.0)[:, 0].tolist() == [0, 0, 0, 2, 2, 128, 255, 255, 255, 0, 0]
 
 
 def test_merged_distance_floor_constant():
@@ -333,3 +336,18 @@ def test_gravity_matches_numpy_restatement(game, oracle, bounds):
         want = NP.gravity_step(want, np.float32(1 / 60), 0.97, law, bounds, t)
     got, _ = oracle.gravity(cin.blob, p, 1 / 60, 3)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_blocked_gravity_loop_equals_scalar_loop(game, oracle):
+    """Constant force laws take an eight-particles-at-a-time loop (AVX2); it must give every particle the bits the
+    one-particle loop gives it, wild positions included."""
+    for bounds in ("reflect", "wrap", "none"):
+        cin = game.compile('cinematic "t" { gravity { rule: 0.7, damping: 0.98, bounds: %s } layer s { circle() | glow() } }' % bounds).cinematics[0]
+        p = oracle.seed_particles(1501, seed=3)
+        p[5, 0] = np.nan
+        p[7, :2] = p[8, :2]
+        p[9, 0] = 1e30
+        p[11, 1] = np.inf
+        a, ta = oracle.gravity(cin.blob, p, 1 / 60, 3, threads=3)
+        b, tb = oracle.gravity(cin.blob, p, 1 / 60, 3, threads=3, blocked=False)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and ta == tb
