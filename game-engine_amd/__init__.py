@@ -73,6 +73,7 @@ def _load():
         "game_ir_default_uniforms": (None, [vp, f32, u32, u32, vp]),
         "game_ir_derived_count": (u32, [vp]),
         "game_ir_pixel_expr_count": (u32, [vp]),
+        "game_ir_project_mode": (c.c_int, [vp]),
         "game_ir_eval_derived": (None, [vp, vp, vp]),
         "game_animator_create": (c.c_int, [vp, c.c_double, c.POINTER(vp)]),
         "game_animator_destroy": (None, [vp]),
@@ -130,10 +131,12 @@ SEMANTICS = {"glsl": 0, "wgsl": 1}   # GAME_HIP_SEMANTICS_WGSL
 ANIMATE_ARGS = 2                     # GAME_HIP_ANIMATE_ARGS
 LENS_POST = 4                        # GAME_HIP_LENS_POST
 GRAVITY_FAST = 8                     # GAME_HIP_GRAVITY_FAST
+PROJECT = 16                         # GAME_HIP_PROJECT
 
 
-def _flags(semantics, animate, lens_post, gravity_fast=False):
-    return SEMANTICS[semantics] | (ANIMATE_ARGS if animate else 0) | (LENS_POST if lens_post else 0) | (GRAVITY_FAST if gravity_fast else 0)
+def _flags(semantics, animate, lens_post, gravity_fast=False, project=False):
+    return (SEMANTICS[semantics] | (ANIMATE_ARGS if animate else 0) | (LENS_POST if lens_post else 0) |
+            (GRAVITY_FAST if gravity_fast else 0) | (PROJECT if project else 0))
 
 
 def _check(rc):
@@ -230,21 +233,27 @@ class Cinematic:
         """Stateful host-side animation of the user uniforms: arcs, `~` modulation, temporal operators, resonance."""
         return Animator(self, fps)
 
-    def compile_only(self, semantics="glsl", animate=False, lens_post=False):
+    @property
+    def project_mode(self):
+        """None, or the mode of the project block that names this cinematic: "flat", "dome", "cube", "led"."""
+        m = lib.game_ir_project_mode(self._h)
+        return None if m < 0 else ("flat", "dome", "cube", "led")[m]
+
+    def compile_only(self, semantics="glsl", animate=False, lens_post=False, project=False):
         """hiprtc-compiles the generated kernels for gfx950 without a device; returns code bytes."""
         n = ctypes.c_size_t()
-        _check(lib.game_hip_compile_only_ex(self._h, _flags(semantics, animate, lens_post), ctypes.byref(n)))
+        _check(lib.game_hip_compile_only_ex(self._h, _flags(semantics, animate, lens_post, project=project), ctypes.byref(n)))
         return n.value
 
     def dump_code(self, path_prefix):
         """Writes the generated kernel source and gfx950 code object next to `path_prefix`."""
         _check(lib.game_hip_dump_code(self._h, path_prefix.encode()))
 
-    def renderer(self, w, h, device=0, semantics="glsl", animate=False, lens_post=False, gravity_fast=False):
+    def renderer(self, w, h, device=0, semantics="glsl", animate=False, lens_post=False, gravity_fast=False, project=False):
         """semantics: "glsl" = the reference's WebGL2 wording of the builtins (default), "wgsl" = its WebGPU wording.
         animate: expression-valued stage arguments take their per-frame value instead of the parameter default.
         lens_post: the `lens { post: ... }` chain runs on the composited colour (the reference ignores it)."""
-        return Renderer(self, w, h, device, semantics, animate, lens_post, gravity_fast)
+        return Renderer(self, w, h, device, semantics, animate, lens_post, gravity_fast, project)
 
 
 class Program:
@@ -391,11 +400,11 @@ class Animator:
 class Renderer:
     """GPU context for one cinematic at one resolution (reference: GameRendererGL, runtime/helpers.rs:131-241)."""
 
-    def __init__(self, cinematic, w, h, device=0, semantics="glsl", animate=False, lens_post=False, gravity_fast=False):
+    def __init__(self, cinematic, w, h, device=0, semantics="glsl", animate=False, lens_post=False, gravity_fast=False, project=False):
         self.cinematic = cinematic
         self.w, self.h = w, h
         h_ = ctypes.c_void_p()
-        _check(lib.game_hip_create_ex(cinematic._h, w, h, device, _flags(semantics, animate, lens_post, gravity_fast), ctypes.byref(h_)))
+        _check(lib.game_hip_create_ex(cinematic._h, w, h, device, _flags(semantics, animate, lens_post, gravity_fast, project), ctypes.byref(h_)))
         self._h = h_
 
     def close(self):

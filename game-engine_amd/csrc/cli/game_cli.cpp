@@ -12,7 +12,8 @@
 //                                        --out - writes the frames as raw RGBA8 to stdout, top row first (for a pipe
 //                                        into an encoder, e.g. ffmpeg -f rawvideo -pix_fmt rgba -s WxH -r FPS -i -);
 //                                        the cinematic's arc timeline (runtime/arc.rs) drives its parameters unless
-//                                        --no-arcs; --animate evaluates expression-valued stage arguments per frame
+//                                        --no-arcs; --animate evaluates expression-valued stage arguments per frame;
+//                                        --project applies the projection block that names the cinematic
 //                                        (the reference's emitters use the parameter defaults) and runs `~` modulation
 //                                        and the temporal operators of the parameters on the host; --semantics wgsl renders the builtins as the reference's WebGPU emitter
 //                                        words them (wgsl.rs:268-540) instead of its WebGL2 emitter
@@ -56,7 +57,7 @@ int usage()
             "usage: game check FILE...\n"
             "       game render FILE --hip [--size WxH] [--frames N] [--fps F] [--batch B] [--device D]\n"
             "                   [--cinematic I] [--out PREFIX|-] [--particles N --steps S]\n"
-            "                   [--png] [--semantics glsl|wgsl] [--no-arcs] [--animate] [--lens-post] [--imports] [--lib DIR]... [--json] [--gpus N]\n"
+            "                   [--png] [--semantics glsl|wgsl] [--no-arcs] [--animate] [--lens-post] [--project] [--imports] [--lib DIR]... [--json] [--gpus N]\n"
             "       game compare A B [--threshold T]\n"
             "       game ir FILE | game kernel FILE [--size WxH] | game builtins\n");
     return 2;
@@ -64,7 +65,7 @@ int usage()
 
 struct Args {
     std::vector<std::string> files;
-    bool hip = false, png = false, wgsl = false, arcs = true, animate = false, lens_post = false, json = false;
+    bool hip = false, png = false, wgsl = false, arcs = true, animate = false, lens_post = false, project = false, json = false;
     int threshold = 2;
     uint32_t w = 1920, h = 1080, frames = 60, batch = 16, cinematic = 0, particles = 0, steps = 1, gpus = 1;
     double fps = 60.0;
@@ -87,6 +88,7 @@ bool parse_args(int argc, char** argv, int first, Args& a)
         else if (s == "--no-arcs") a.arcs = false;
         else if (s == "--animate") a.animate = true;
         else if (s == "--lens-post") a.lens_post = true;
+        else if (s == "--project") a.project = true;
         else if (s == "--json") a.json = true;
         else if (s == "--semantics") {
             const char* v = value("--semantics");
@@ -396,7 +398,7 @@ int cmd_render(const Args& a)
     do {
         if (a.cinematic >= game_program_cinematic_count(prog)) { fprintf(stderr, "game render: no cinematic %u\n", a.cinematic); break; }
         const game_ir* ir = game_program_ir(prog, a.cinematic);
-        if (game_hip_create_ex(ir, a.w, a.h, a.device, (a.wgsl ? (uint32_t)GAME_HIP_SEMANTICS_WGSL : 0u) | (a.animate ? (uint32_t)GAME_HIP_ANIMATE_ARGS : 0u) | (a.lens_post ? (uint32_t)GAME_HIP_LENS_POST : 0u), &ctx) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
+        if (game_hip_create_ex(ir, a.w, a.h, a.device, (a.wgsl ? (uint32_t)GAME_HIP_SEMANTICS_WGSL : 0u) | (a.animate ? (uint32_t)GAME_HIP_ANIMATE_ARGS : 0u) | (a.lens_post ? (uint32_t)GAME_HIP_LENS_POST : 0u) | (a.project ? (uint32_t)GAME_HIP_PROJECT : 0u), &ctx) != GAME_OK) { fprintf(stderr, "game render: %s\n", game_last_error()); break; }
         if (a.particles) {
             if (game_hip_particles_seed(ctx, a.particles, 0x9E3779B97F4A7C15ull) != GAME_OK ||
                 game_hip_particles_step(ctx, (float)(1.0 / a.fps), a.steps, 0, a.particles) != GAME_OK || game_hip_sync(ctx) != GAME_OK) {
@@ -410,7 +412,7 @@ int cmd_render(const Args& a)
             rc = 0;
             break;
         }
-        const uint32_t flags = (a.wgsl ? (uint32_t)GAME_HIP_SEMANTICS_WGSL : 0u) | (a.animate ? (uint32_t)GAME_HIP_ANIMATE_ARGS : 0u) | (a.lens_post ? (uint32_t)GAME_HIP_LENS_POST : 0u);
+        const uint32_t flags = (a.wgsl ? (uint32_t)GAME_HIP_SEMANTICS_WGSL : 0u) | (a.animate ? (uint32_t)GAME_HIP_ANIMATE_ARGS : 0u) | (a.lens_post ? (uint32_t)GAME_HIP_LENS_POST : 0u) | (a.project ? (uint32_t)GAME_HIP_PROJECT : 0u);
         auto t0 = std::chrono::steady_clock::now();
         double device_ms = 0;
         if (a.gpus <= 1) {

@@ -147,6 +147,7 @@ void game_ir_default_uniforms(const game_ir* ir, float time_s, uint32_t w, uint3
 }
 
 uint32_t game_ir_derived_count(const game_ir* ir) { return ir ? (uint32_t)ir->ir->derived.size() : 0; }
+int game_ir_project_mode(const game_ir* ir) { return ir && ir->ir->project.present ? (int)ir->ir->project.mode : -1; }
 uint32_t game_ir_pixel_expr_count(const game_ir* ir) { return ir ? (uint32_t)ir->ir->pixel_exprs.size() : 0; }
 
 void game_ir_eval_derived(const game_ir* ir, const float* row, float* out)

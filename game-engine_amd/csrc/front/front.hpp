@@ -232,7 +232,8 @@ struct IrLayer {
 enum LawOp : uint32_t { LAW_NUM = 0, LAW_DIST, LAW_TIME, LAW_ADD, LAW_SUB, LAW_MUL, LAW_DIV, LAW_POW, LAW_GT, LAW_LT,
                         LAW_NEG, LAW_CALL1, LAW_CALL2, LAW_CALL3, LAW_UNIFORM, LAW_PX, LAW_PY, LAW_UVX, LAW_UVY };
 enum LawFn : uint32_t { LF_SIN = 0, LF_COS, LF_TAN, LF_ABS, LF_SQRT, LF_EXP, LF_LOG, LF_FLOOR, LF_CEIL, LF_FRACT, LF_SIGN,
-                        LF_MIN, LF_MAX, LF_POW, LF_STEP, LF_CLAMP, LF_MIX, LF_SMOOTHSTEP, LF_EXP2, LF_LOG2, LF_COUNT };
+                        LF_MIN, LF_MAX, LF_POW, LF_STEP, LF_CLAMP, LF_MIX, LF_SMOOTHSTEP, LF_EXP2, LF_LOG2,
+                        LF_ROUND, LF_MOD, LF_ATAN2, LF_LENGTH2, LF_COUNT };
 struct IrLawOp { uint32_t op = LAW_NUM; float val = 0.0f; uint32_t fn = 0; };
 struct IrGravity {
     bool present = false;
@@ -240,6 +241,18 @@ struct IrGravity {
     Bounds bounds = Bounds::Reflect;
     std::vector<IrLawOp> law;     // postfix program over {dist, time}
     std::string law_text;         // as printed into WGSL by the reference
+};
+// `project <mode> (params) { source: name }` (codegen/project.rs): the reference replaces the WebGPU vertex stage, which
+// changes the v_uv every fragment starts from. Here it is a per-pixel warp of v_uv before the layers run.
+//   flat, cube: v_uv unchanged (cube only adds a face index the fragment stage never reads, project.rs:79-110)
+//   dome      : fisheye, project.rs:62-69 (fov_deg from the parameter fov / fov_deg / fisheye, default 180)
+//   led       : every pixel of LED k = floor(v_uv.x * count) samples (k / count, 0.5), project.rs:128-137
+//               (count from the parameter count / leds, default 60)
+struct IrProject {
+    bool present = false;
+    ProjectMode mode = ProjectMode::Flat;
+    float fov_deg = 180.0f;
+    uint32_t count = 60;
 };
 // One entry of the arc timeline (runtime/arc.rs:52-125): uniform `idx` moves from `from` to `to` over
 // [start, start + dur) seconds through `easing`; entries run back to back in source order. idx < 0: the
@@ -277,6 +290,7 @@ struct Ir {
     std::vector<IrDerived> pixel_exprs;   // programs that also use LAW_PX / LAW_PY / LAW_UVX / LAW_UVY
     std::vector<IrParamAnim> anims;
     std::vector<IrResonance> resonances;
+    IrProject project;
 };
 
 // Value of a frame-level program over one frame row, binary64. wrap_time: `time` is the shader's wrapped f32

@@ -66,8 +66,8 @@ LawFn law_fn(const std::string& n, size_t nargs, bool& ok)
     static const E tab[] = {
         {"sin", LF_SIN, 1}, {"cos", LF_COS, 1}, {"tan", LF_TAN, 1}, {"abs", LF_ABS, 1}, {"sqrt", LF_SQRT, 1},
         {"exp", LF_EXP, 1}, {"log", LF_LOG, 1}, {"floor", LF_FLOOR, 1}, {"ceil", LF_CEIL, 1}, {"fract", LF_FRACT, 1},
-        {"sign", LF_SIGN, 1}, {"exp2", LF_EXP2, 1}, {"log2", LF_LOG2, 1},
-        {"min", LF_MIN, 2}, {"max", LF_MAX, 2}, {"pow", LF_POW, 2}, {"step", LF_STEP, 2},
+        {"sign", LF_SIGN, 1}, {"exp2", LF_EXP2, 1}, {"log2", LF_LOG2, 1}, {"round", LF_ROUND, 1},
+        {"min", LF_MIN, 2}, {"max", LF_MAX, 2}, {"pow", LF_POW, 2}, {"step", LF_STEP, 2}, {"mod", LF_MOD, 2}, {"atan2", LF_ATAN2, 2},
         {"clamp", LF_CLAMP, 3}, {"mix", LF_MIX, 3}, {"smoothstep", LF_SMOOTHSTEP, 3},
     };
     for (const E& e : tab) if (n == e.n && nargs == e.a) { ok = true; return e.f; }
@@ -118,6 +118,11 @@ std::string expr_source_text(const Expr& e)
     case Expr::Ident: return e.s;
     case Expr::Dotted: return e.s + "." + e.field;
     case Expr::Paren: return "(" + expr_source_text(e.kids[0]) + ")";
+    case Expr::Array: {
+        std::string t = "[";
+        for (size_t i = 0; i < e.kids.size(); ++i) t += (i ? ", " : "") + expr_source_text(e.kids[i]);
+        return t + "]";
+    }
     case Expr::Neg: return "-" + expr_source_text(e.kids[0]);
     case Expr::Bin: {
         static const char* const ops[] = {" + ", " - ", " * ", " / ", " ^ ", " > ", " < "};
@@ -132,53 +137,144 @@ std::string expr_source_text(const Expr& e)
     }
 }
 
-// Frame-level scalar expression -> RPN; false when it reads something that is not a frame constant
-// (`p`, `uv`, an unknown name, a string, an array) or calls an unknown function.
-bool lower_frame_expr(const Expr& e, const std::map<std::string, uint32_t>& uslot, std::vector<IrLawOp>& prog, bool allow_pixel = false)
+// A lowered (sub)expression: one postfix program for a scalar, two (x and y component) for a vec2. Vector values
+// exist only while lowering: `p`, `uv`, two-element arrays and the operators / functions over them (expr.rs:50-144
+// words them as WGSL vec2f arithmetic) are expanded component by component, so what reaches the IR is always a
+// scalar program. length(v) becomes the two-argument function length2(x, y); dot, distance and normalize expand to
+// their defining sums, differences and quotients.
+struct LoweredValue {
+    bool vec = false;
+    std::vector<IrLawOp> x, y;
+    const std::vector<IrLawOp>& comp(int c) const { return vec && c == 1 ? y : x; }
+};
+
+void append(std::vector<IrLawOp>& dst, const std::vector<IrLawOp>& src) { dst.insert(dst.end(), src.begin(), src.end()); }
+IrLawOp law_op(uint32_t op, float v = 0.0f, uint32_t fn = 0) { IrLawOp o; o.op = op; o.val = v; o.fn = fn; return o; }
+
+bool lower_value(const Expr& e, const std::map<std::string, uint32_t>& uslot, bool allow_pixel, LoweredValue& out)
 {
-    auto push = [&](uint32_t op, float v = 0.0f, uint32_t fn = 0) { IrLawOp o; o.op = op; o.val = v; o.fn = fn; prog.push_back(o); };
+    out = LoweredValue{};
     switch (e.kind) {
-    case Expr::Number: push(LAW_NUM, (float)e.num); return true;
-    case Expr::Dur: push(LAW_NUM, (float)(e.dur.kind == DurKind::Seconds ? e.dur.v : e.dur.kind == DurKind::Millis ? e.dur.v / 1000.0 : (double)e.dur.bars * 2.0)); return true;
+    case Expr::Number: out.x.push_back(law_op(LAW_NUM, (float)e.num)); return true;
+    case Expr::Dur:
+        out.x.push_back(law_op(LAW_NUM, (float)(e.dur.kind == DurKind::Seconds ? e.dur.v : e.dur.kind == DurKind::Millis ? e.dur.v / 1000.0 : (double)e.dur.bars * 2.0)));
+        return true;
     case Expr::Ident: {
-        if (e.s == "time") { push(LAW_UNIFORM, 0.0f, BU_TIME); return true; }
+        if (e.s == "time") { out.x.push_back(law_op(LAW_UNIFORM, 0.0f, BU_TIME)); return true; }
         static const struct { const char* n; float v; } consts[] = {   // expr.rs:39-47
             {"pi", 3.14159265358979f}, {"tau", 6.28318530717959f}, {"e", 2.71828182845905f}, {"phi", 1.61803398874989f}};
-        for (auto& k : consts) if (e.s == k.n) { push(LAW_NUM, k.v); return true; }
+        for (auto& k : consts) if (e.s == k.n) { out.x.push_back(law_op(LAW_NUM, k.v)); return true; }
         auto it = uslot.find(e.s);
-        if (it == uslot.end()) return false;
-        push(LAW_UNIFORM, 0.0f, BU_COUNT + it->second);
-        return true;
+        if (it != uslot.end()) { out.x.push_back(law_op(LAW_UNIFORM, 0.0f, BU_COUNT + it->second)); return true; }
+        if (allow_pixel && (e.s == "p" || e.s == "uv")) {   // the position / the normalised pixel coordinate as vec2
+            out.vec = true;
+            out.x.push_back(law_op(e.s == "p" ? LAW_PX : LAW_UVX));
+            out.y.push_back(law_op(e.s == "p" ? LAW_PY : LAW_UVY));
+            return true;
+        }
+        return false;
     }
     case Expr::Dotted: {
         static const struct { const char* o; const char* f; uint32_t slot; } dotted[] = {
             {"audio", "bass", BU_AUDIO_BASS}, {"audio", "mid", BU_AUDIO_MID}, {"audio", "treble", BU_AUDIO_TREBLE},
             {"audio", "energy", BU_AUDIO_ENERGY}, {"audio", "beat", BU_AUDIO_BEAT}, {"mouse", "x", BU_MOUSE_X}, {"mouse", "y", BU_MOUSE_Y}};
-        for (auto& d : dotted) if (e.s == d.o && e.field == d.f) { push(LAW_UNIFORM, 0.0f, d.slot); return true; }
+        for (auto& d : dotted) if (e.s == d.o && e.field == d.f) { out.x.push_back(law_op(LAW_UNIFORM, 0.0f, d.slot)); return true; }
         if (allow_pixel && (e.s == "p" || e.s == "uv") && (e.field == "x" || e.field == "y")) {
-            push(e.s == "p" ? (e.field == "x" ? LAW_PX : LAW_PY) : (e.field == "x" ? LAW_UVX : LAW_UVY));
+            out.x.push_back(law_op(e.s == "p" ? (e.field == "x" ? LAW_PX : LAW_PY) : (e.field == "x" ? LAW_UVX : LAW_UVY)));
             return true;
         }
         return false;
     }
-    case Expr::Paren: return lower_frame_expr(e.kids[0], uslot, prog, allow_pixel);
-    case Expr::Neg: if (!lower_frame_expr(e.kids[0], uslot, prog, allow_pixel)) return false; push(LAW_NEG); return true;
+    case Expr::Array: {   // [a, b] -> vec2f(a, b) (expr.rs:70-81); longer arrays have no scalar use here
+        if (e.kids.size() != 2) return false;
+        LoweredValue a, b;
+        if (!lower_value(e.kids[0], uslot, allow_pixel, a) || !lower_value(e.kids[1], uslot, allow_pixel, b) || a.vec || b.vec) return false;
+        out.vec = true; out.x = a.x; out.y = b.x;
+        return true;
+    }
+    case Expr::Paren: return lower_value(e.kids[0], uslot, allow_pixel, out);
+    case Expr::Neg: {
+        if (!lower_value(e.kids[0], uslot, allow_pixel, out)) return false;
+        out.x.push_back(law_op(LAW_NEG));
+        if (out.vec) out.y.push_back(law_op(LAW_NEG));
+        return true;
+    }
     case Expr::Bin: {
-        if (!lower_frame_expr(e.kids[0], uslot, prog, allow_pixel) || !lower_frame_expr(e.kids[1], uslot, prog, allow_pixel)) return false;
+        LoweredValue l, r;
+        if (!lower_value(e.kids[0], uslot, allow_pixel, l) || !lower_value(e.kids[1], uslot, allow_pixel, r)) return false;
         static const uint32_t ops[] = {LAW_ADD, LAW_SUB, LAW_MUL, LAW_DIV, LAW_POW, LAW_GT, LAW_LT};
-        push(ops[(int)e.op]);
+        const uint32_t op = ops[(int)e.op];
+        out.vec = l.vec || r.vec;
+        if (out.vec && (op == LAW_GT || op == LAW_LT)) return false;   // a vec2<bool> has no scalar meaning as an argument
+        for (int c = 0; c < (out.vec ? 2 : 1); ++c) {                  // a scalar operand is broadcast
+            std::vector<IrLawOp>& dst = c ? out.y : out.x;
+            append(dst, l.comp(c)); append(dst, r.comp(c)); dst.push_back(law_op(op));
+        }
         return true;
     }
     case Expr::Call: {
+        std::vector<LoweredValue> args(e.args.size());
+        bool any_vec = false;
+        for (size_t i = 0; i < e.args.size(); ++i) {
+            if (!lower_value(e.args[i].value, uslot, allow_pixel, args[i])) return false;
+            any_vec = any_vec || args[i].vec;
+        }
+        auto sub = [&](const LoweredValue& a, const LoweredValue& b, int c, std::vector<IrLawOp>& dst) {
+            append(dst, a.comp(c)); append(dst, b.comp(c)); dst.push_back(law_op(LAW_SUB));
+        };
+        if (e.s == "length" && args.size() == 1) {
+            if (!args[0].vec) { out.x = args[0].x; out.x.push_back(law_op(LAW_CALL1, 0.0f, LF_ABS)); return true; }
+            append(out.x, args[0].x); append(out.x, args[0].y); out.x.push_back(law_op(LAW_CALL2, 0.0f, LF_LENGTH2));
+            return true;
+        }
+        if (e.s == "distance" && args.size() == 2) {
+            if (!any_vec) { sub(args[0], args[1], 0, out.x); out.x.push_back(law_op(LAW_CALL1, 0.0f, LF_ABS)); return true; }
+            sub(args[0], args[1], 0, out.x); sub(args[0], args[1], 1, out.x); out.x.push_back(law_op(LAW_CALL2, 0.0f, LF_LENGTH2));
+            return true;
+        }
+        if (e.s == "dot" && args.size() == 2) {
+            append(out.x, args[0].comp(0)); append(out.x, args[1].comp(0)); out.x.push_back(law_op(LAW_MUL));
+            if (any_vec) {
+                append(out.x, args[0].comp(1)); append(out.x, args[1].comp(1)); out.x.push_back(law_op(LAW_MUL));
+                out.x.push_back(law_op(LAW_ADD));
+            }
+            return true;
+        }
+        if (e.s == "normalize" && args.size() == 1 && args[0].vec) {   // v * (1 / length(v))
+            out.vec = true;
+            for (int c = 0; c < 2; ++c) {
+                std::vector<IrLawOp>& dst = c ? out.y : out.x;
+                append(dst, args[0].comp(c));
+                dst.push_back(law_op(LAW_NUM, 1.0f));
+                append(dst, args[0].x); append(dst, args[0].y); dst.push_back(law_op(LAW_CALL2, 0.0f, LF_LENGTH2));
+                dst.push_back(law_op(LAW_DIV));
+                dst.push_back(law_op(LAW_MUL));
+            }
+            return true;
+        }
         bool ok;
         LawFn f = law_fn(e.s, e.args.size(), ok);
         if (!ok) return false;
-        for (const Arg& a : e.args) if (!lower_frame_expr(a.value, uslot, prog, allow_pixel)) return false;
-        push(e.args.size() == 1 ? LAW_CALL1 : e.args.size() == 2 ? LAW_CALL2 : LAW_CALL3, 0.0f, f);
+        out.vec = any_vec;                                              // component-wise, scalar arguments broadcast
+        for (int c = 0; c < (out.vec ? 2 : 1); ++c) {
+            std::vector<IrLawOp>& dst = c ? out.y : out.x;
+            for (const LoweredValue& a : args) append(dst, a.comp(c));
+            dst.push_back(law_op(args.size() == 1 ? LAW_CALL1 : args.size() == 2 ? LAW_CALL2 : LAW_CALL3, 0.0f, f));
+        }
         return true;
     }
     default: return false;
     }
+}
+
+// Frame-level scalar expression -> RPN; false when it reads something that is not a frame constant
+// (`p`, `uv` unless allow_pixel, an unknown name, a string), calls an unknown function, or is vector-valued.
+bool lower_frame_expr(const Expr& e, const std::map<std::string, uint32_t>& uslot, std::vector<IrLawOp>& prog, bool allow_pixel = false)
+{
+    LoweredValue v;
+    if (!lower_value(e, uslot, allow_pixel, v) || v.vec) return false;
+    append(prog, v.x);
+    return true;
 }
 
 }  // namespace
@@ -192,7 +288,8 @@ double eval_frame_prog(const std::vector<IrLawOp>& prog, const float* row, bool 
         case LF_SIN: return sin(a); case LF_COS: return cos(a); case LF_TAN: return tan(a); case LF_ABS: return fabs(a);
         case LF_SQRT: return sqrt(a); case LF_EXP: return exp(a); case LF_LOG: return log(a); case LF_FLOOR: return floor(a);
         case LF_CEIL: return ceil(a); case LF_FRACT: return a - floor(a); case LF_SIGN: return a > 0.0 ? 1.0 : a < 0.0 ? -1.0 : 0.0;
-        case LF_EXP2: return exp2(a); case LF_LOG2: return log2(a);
+        case LF_EXP2: return exp2(a); case LF_LOG2: return log2(a); case LF_ROUND: return nearbyint(a);
+        case LF_MOD: return a - b * trunc(a / b); case LF_ATAN2: return atan2(a, b); case LF_LENGTH2: return sqrt(a * a + b * b);
         case LF_MIN: return a < b ? a : b; case LF_MAX: return a > b ? a : b; case LF_POW: return pow(a, b);
         case LF_STEP: return b < a ? 0.0 : 1.0;
         case LF_CLAMP: { double lo = a > b ? a : b; return lo < c ? lo : c; }
@@ -391,7 +488,7 @@ Ir lower_cinematic(const Cinematic& c)
                     ir.derived.push_back(std::move(d));
                 } else {
                     d.prog.clear();   // not a frame constant: maybe a function of the pixel as well
-                    if (lower_frame_expr(*t.dropped, uslot, d.prog, true) && d.prog.size() < 48 && ir.pixel_exprs.size() < 0xfffe) {
+                    if (lower_frame_expr(*t.dropped, uslot, d.prog, true) && d.prog.size() < 120 && ir.pixel_exprs.size() < 0xfffe) {
                         d.text = expr_source_text(*t.dropped);
                         a.pixel = (int)ir.pixel_exprs.size();
                         ir.pixel_exprs.push_back(std::move(d));
@@ -732,6 +829,11 @@ std::vector<uint8_t> ir_serialize(const Ir& ir)
             put_u32(b, 0);
         }
     }
+    // trailing section: the projection block that names this cinematic (mode + 1, 0 = none)
+    put_u32(b, ir.project.present ? (uint32_t)ir.project.mode + 1u : 0u);
+    put_f32(b, ir.project.fov_deg);
+    put_u32(b, ir.project.count);
+    put_u32(b, 0);
     uint32_t total = (uint32_t)b.size();
     for (int i = 0; i < 4; ++i) b[4 + i] = (uint8_t)(total >> (8 * i));
     return b;
@@ -813,7 +915,15 @@ std::string ir_to_json(const Ir& ir)
                  a.idx < 0 ? 0.0 : a.from, a.idx < 0 ? 0.0 : a.to, a.start, a.dur);
         j += (i ? "," : "") + std::string(buf) + "\"target\":\"" + json_escape(a.target) + "\",\"ease\":\"" + json_escape(a.easing) + "\"}";
     }
-    j += "]}";
+    j += "]";
+    if (ir.project.present) {
+        static const char* modes[] = {"flat", "dome", "cube", "led"};
+        char buf[128];
+        snprintf(buf, sizeof buf, ",\"project\":{\"mode\":\"%s\",\"fov_deg\":%.9g,\"count\":%u}", modes[(int)ir.project.mode],
+                 (double)ir.project.fov_deg, ir.project.count);
+        j += buf;
+    }
+    j += "}";
     return j;
 }
 
@@ -838,6 +948,20 @@ CompileError compile_impl(const std::string& src, const std::string* base_dir, c
         e = validate_cinematic(c);
         if (!e.ok()) return e;
         out.irs.push_back(lower_cinematic(c));
+        // the first project block whose source names this cinematic (lib.rs:187-192 overrides that output's vertex stage)
+        for (const ProjectBlock& pb : out.ast.projects) {
+            if (pb.source != c.name) continue;
+            IrProject& pr = out.irs.back().project;
+            pr.present = true;
+            pr.mode = pb.mode;
+            for (const Param& prm : pb.params) {
+                double v = 0.0;
+                if (!eval_js_const(prm.value, v)) continue;
+                if (prm.name == "fov" || prm.name == "fov_deg" || prm.name == "fisheye") pr.fov_deg = (float)v;
+                else if ((prm.name == "count" || prm.name == "leds") && v >= 1.0 && v <= 1048576.0) pr.count = (uint32_t)v;
+            }
+            break;
+        }
         out.blobs.push_back(ir_serialize(out.irs.back()));
         out.jsons.push_back(ir_to_json(out.irs.back()));
     }

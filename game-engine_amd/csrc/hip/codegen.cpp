@@ -28,7 +28,7 @@ namespace {
 std::string rpn_expr(const std::vector<IrLawOp>& prog, bool gravity)
 {
     static const char* fn1[] = {"gd_sin", "gd_cos", "gd_tan", "gd_abs", "gd_sqrt", "gd_exp", "gd_log", "gd_floor", "gd_ceil",
-                                "gd_fract", "gd_sign", "", "", "", "", "", "", "", "gd_exp2", "gd_log2"};
+                                "gd_fract", "gd_sign", "", "", "", "", "", "", "", "gd_exp2", "gd_log2", "gd_round"};
     std::vector<std::string> st;
     if (prog.empty()) return "1.0f";
     for (const IrLawOp& o : prog) {
@@ -53,7 +53,8 @@ std::string rpn_expr(const std::vector<IrLawOp>& prog, bool gravity)
         case LAW_CALL1: { auto v = pop(); st.push_back(std::string(fn1[o.fn]) + "(" + v + ")"); break; }
         case LAW_CALL2: {
             auto b = pop(), a = pop();
-            const char* f = o.fn == LF_MIN ? "gd_min" : o.fn == LF_MAX ? "gd_max" : o.fn == LF_POW ? "gd_pow" : "gd_step";
+            const char* f = o.fn == LF_MIN ? "gd_min" : o.fn == LF_MAX ? "gd_max" : o.fn == LF_POW ? "gd_pow" : o.fn == LF_MOD ? "gw_rem" :
+                            o.fn == LF_ATAN2 ? "gd_atan2" : o.fn == LF_LENGTH2 ? "gd_length2" : "gd_step";
             st.push_back(std::string(f) + "(" + a + ", " + b + ")");
             break;
         }
@@ -253,6 +254,16 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
             k += "    const gd_u32 prev = P.prev ? P.prev[(unsigned long long)ty * P.w + x] : 0u;\n";
     }
     k += "    const float vx = ((float)x + 0.5f) * P.inv_w;\n";
+    const bool warp = shape.project && ir.project.present && (ir.project.mode == ProjectMode::Dome || ir.project.mode == ProjectMode::Led);
+    if (warp) {
+        // projection block: the fragment starts from a warped v_uv (project.rs:62-69 dome, :128-137 led)
+        k += "    float wvx, wvy;\n";
+        if (ir.project.mode == ProjectMode::Dome)
+            k += "    gd_project_dome(vx, vy, " + float_literal(ir.project.fov_deg * 3.14159265359f / 180.0f) + ", wvx, wvy);\n";
+        else
+            k += "    gd_project_led(vx, " + float_literal((float)ir.project.count) + ", wvx, wvy);\n";
+        k += "    s.uvx = wvx * 2.0f - 1.0f;\n    s.uvy = wvy * 2.0f - 1.0f;\n";
+    } else
     k += "    s.uvx = vx * 2.0f - 1.0f;\n";
     bool reads_uv_length = false;
     for (const IrLayer& L : ir.layers) {

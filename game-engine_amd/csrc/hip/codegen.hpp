@@ -13,6 +13,7 @@ struct KernelShape {
     bool animate = false;           // expression-valued stage arguments read their per-frame value (Ir::derived)
     uint32_t derived_slot = 0;      // index in the frame row of derived value 0
     bool lens_post = false;         // run the lens post chain on the composited colour
+    bool project = false;           // apply the cinematic's projection block (Ir::project) to v_uv
     uint32_t wg = 256;              // threads per workgroup (a multiple of 64)
 };
 

@@ -95,6 +95,7 @@ GD float gd_rcp(float y)
 GD float gd_mod(float x, float y) { return x - y * gd_floor(x * gd_rcp(y)); }
 GD float gd_step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
 GD float gd_ceil(float x) { return -gd_floor(-x); }
+GD float gd_round(float x) { return __builtin_rintf(x); }   // to nearest, ties to even (v_rndne_f32)
 GD float gd_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 GD float gd_mix(float a, float b, float t) { return __builtin_fmaf(b, t, a * (1.0f - t)); }
 GD float gd_smoothstep(float e0, float e1, float x)
@@ -513,6 +514,25 @@ struct GdPix {
     const float* vlut;     // voronoi feature-point table (uniform; may be null)
     const float* slut;     // simplex corner table (uniform; may be null)
 };
+
+// Projection blocks (game-compiler/src/codegen/project.rs): warps of v_uv applied before the layers run.
+GD void gd_project_dome(float vx, float vy, float fov_rad, float& ox, float& oy)   // project.rs:62-69
+{
+    float cx = vx - 0.5f, cy = vy - 0.5f;
+    float r = gd_length2(cx, cy) * 2.0f;
+    float theta = gd_atan2(cy, cx);
+    float phi = r * fov_rad * 0.5f;
+    float sp = gd_sin(phi);
+    float st, ct;
+    gd_sincos(theta, st, ct);
+    ox = sp * ct * 0.5f + 0.5f;
+    oy = sp * st * 0.5f + 0.5f;
+}
+GD void gd_project_led(float vx, float count, float& ox, float& oy)                // project.rs:128-137
+{
+    ox = gd_floor(vx * count) / count;   // t = f32(led_idx) / f32(count)
+    oy = 0.5f;
+}
 
 // length(uv) and its reciprocal, both correctly rounded, once per pixel: vignette and chromatic (and their WebGPU
 // wordings) all start from length(uv), and normalize(uv) is uv * (1 / length(uv)). uv = 0 gives 0 and +inf.

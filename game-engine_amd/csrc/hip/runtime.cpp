@@ -229,6 +229,7 @@ KernelShape shape_for(const Ir& ir, uint32_t width, uint32_t flags = 0)
     s.animate = (flags & GAME_HIP_ANIMATE_ARGS) != 0 && (!ir.derived.empty() || !ir.pixel_exprs.empty());
     s.derived_slot = row + 2;
     s.lens_post = (flags & GAME_HIP_LENS_POST) != 0;
+    s.project = (flags & GAME_HIP_PROJECT) != 0;
     return s;
 }
 
@@ -479,7 +480,7 @@ int game_hip_create(const game_ir* ir, uint32_t width, uint32_t height, int devi
 int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int device, uint32_t flags, game_hip_ctx** out)
 {
     if (!ir || !out) return set_error(GAME_E_ARGUMENT, "game_hip_create: null argument");
-    if (flags & ~(uint32_t)(GAME_HIP_SEMANTICS_WGSL | GAME_HIP_ANIMATE_ARGS | GAME_HIP_LENS_POST | GAME_HIP_GRAVITY_FAST))
+    if (flags & ~(uint32_t)(GAME_HIP_SEMANTICS_WGSL | GAME_HIP_ANIMATE_ARGS | GAME_HIP_LENS_POST | GAME_HIP_GRAVITY_FAST | GAME_HIP_PROJECT))
         return set_error(GAME_E_ARGUMENT, "game_hip_create_ex: unknown flag");
     *out = nullptr;
     if (width == 0 || height == 0 || width > 65536 || height > 65535)

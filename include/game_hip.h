@@ -146,6 +146,16 @@ int game_animator_step(game_animator* an, double time_s, double dt, float* row, 
 uint32_t game_ir_arc_count(const game_ir* ir);
 void game_ir_arc_update(const game_ir* ir, double time_s, float* row);
 
+/* `project flat|dome|cube|led (params) { source: name }` (game-compiler/src/codegen/project.rs, applied at lib.rs:187-192):
+ * the reference swaps the WebGPU vertex stage of the cinematic named by `source`, which changes the v_uv its fragments
+ * start from (and leaves its WebGL2 output alone). game_ir_project_mode: -1 = no project block names this cinematic,
+ * 0 flat, 1 dome, 2 cube, 3 led. A context created with GAME_HIP_PROJECT applies the block as a per-pixel warp of
+ * v_uv before the layers run: dome = the fisheye mapping of project.rs:62-69 (evaluated per pixel; the reference
+ * evaluates it at the three vertices of its full-screen triangle, where it degenerates to an affine map), led = every
+ * pixel of LED k = floor(v_uv.x * count) samples (k / count, 0.5) (project.rs:128-137), flat and cube = unchanged. The
+ * memory mix still reads the previous frame at the pixel itself. */
+int game_ir_project_mode(const game_ir* ir);
+
 /* Places where the reference's emitted GLSL does not compile or leaves a value undefined; the IR
  * then carries the evident intent (see front.hpp IrFlag for the per-bit meaning). */
 enum {
@@ -168,6 +178,7 @@ enum {
  *   law op : op, value(f32), fn, 0                                                (16 bytes)
  *   then   : n_pixel_expressions, and per expression its length and that many law ops (ops 14..18 push a frame-row
  *            slot (fn), p.x, p.y, uv.x, uv.y)
+ *   then   : project: mode + 1 (0 = none; 1 flat, 2 dome, 3 cube, 4 led), fov_deg(f32), led count, 0     (16 bytes)
  * Built-in uniform slot 0 used as a stage argument means the shader's wrapped time
  * `fract(u_time / 120) * 120` (glsl.rs:56), not the raw u_time. */
 
@@ -191,7 +202,8 @@ enum {
     /* Gravity step with the pair distance and its reciprocal taken from one hardware reciprocal-square-root
      * (about 1 ulp each) instead of the correctly rounded root and reciprocal of the default build. Not bit-reproducible
      * on a CPU; positions stay within the stated tolerance of the default build (1e-4 relative after 100 steps). */
-    GAME_HIP_GRAVITY_FAST = 8u
+    GAME_HIP_GRAVITY_FAST = 8u,
+    GAME_HIP_PROJECT = 16u        /* see game_ir_project_mode */
 };
 int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int device, uint32_t flags,
                        game_hip_ctx** out);

@@ -44,7 +44,7 @@ class Oracle:
         self.L = L
 
     def render(self, blob, w, h, row, prev=None, row0=0, rows=None, threads=8, semantics="glsl", derived=None,
-               lens_post=False, animate=False):
+               lens_post=False, animate=False, project=False):
         rows = h if rows is None else rows
         row = np.ascontiguousarray(row, dtype=np.float32)
         out = np.zeros((rows, w, 4), dtype=np.uint8)
@@ -55,18 +55,18 @@ class Oracle:
             derived = np.ascontiguousarray(derived, dtype=np.float32)
         rc = self.L.game_oracle_render_ex2(blob, len(blob), w, h, row0, rows, row.ctypes.data,
                                            None if prev is None else prev.ctypes.data, out.ctypes.data, threads,
-                                           {"glsl": 0, "wgsl": 1}[semantics] | (4 if lens_post else 0) | (2 if animate or derived is not None else 0),
+                                           {"glsl": 0, "wgsl": 1}[semantics] | (4 if lens_post else 0) | (2 if animate or derived is not None else 0) | (8 if project else 0),
                                            None if derived is None or derived.size == 0 else derived.ctypes.data)
         assert rc == 0, "oracle rejected the IR blob or arguments"
         return out
 
     def render_sequence(self, blob, w, h, rows_table, uses_memory, row0=0, rows=None, threads=8, semantics="glsl",
-                        derived=None, lens_post=False, animate=False):
+                        derived=None, lens_post=False, animate=False, project=False):
         """derived: None, or one row of expression-argument values per frame."""
         frames, prev = [], None
         for k, r in enumerate(rows_table):
             f = self.render(blob, w, h, r, prev=prev if uses_memory else None, row0=row0, rows=rows, threads=threads,
-                            semantics=semantics, derived=None if derived is None else derived[k], lens_post=lens_post, animate=animate)
+                            semantics=semantics, derived=None if derived is None else derived[k], lens_post=lens_post, animate=animate, project=project)
             frames.append(f)
             prev = f
         return np.stack(frames)

@@ -52,6 +52,9 @@ typedef struct {
     uint32_t n_pix;                              /* stage-argument expressions that read the pixel */
     const ir_law* pix[MAX_PIXEL_EXPRS];
     uint32_t pix_len[MAX_PIXEL_EXPRS];
+    uint32_t project_mode;                       /* 0 none, 1 flat, 2 dome, 3 cube, 4 led (codegen/project.rs) */
+    float project_fov_deg;
+    uint32_t project_count;
 } ir_view;
 
 static int ir_open(const void* blob, size_t len, ir_view* v)
@@ -75,10 +78,13 @@ static int ir_open(const void* blob, size_t len, ir_view* v)
     for (uint32_t i = 0; i < v->n_pix; i++) {
         if (p + 4 > end) return -1;
         memcpy(&v->pix_len[i], p, 4); p += 4;
-        if (v->pix_len[i] > 64 || p + (size_t)v->pix_len[i] * sizeof(ir_law) > end) return -1;
+        if (v->pix_len[i] > 128 || p + (size_t)v->pix_len[i] * sizeof(ir_law) > end) return -1;
         v->pix[i] = (const ir_law*)p; p += (size_t)v->pix_len[i] * sizeof(ir_law);
     }
-    if (p != end) return -1;
+    /* trailing section: the projection block (mode + 1, fov_deg, led count, pad) */
+    if (p + 16 != end) return -1;
+    memcpy(&v->project_mode, p, 4); memcpy(&v->project_fov_deg, p + 4, 4); memcpy(&v->project_count, p + 8, 4);
+    if (v->project_mode > 4) return -1;
     return 0;
 }
 
@@ -207,6 +213,7 @@ static const float PALETTES[8][12] = {
 /* ── one pixel ─────────────────────────────────────────────────────────────────────────── */
 typedef struct {
     int wgsl;        /* builtins as worded by the WebGPU emitter (wgsl.rs:268-540) where they differ */
+    int project;     /* apply the projection block to v_uv (game-compiler/src/codegen/project.rs) */
     int lens_post;   /* run the lens post chain (the layer marked pad0 = 1) on the composited colour; the reference's
                         emitters ignore the chain, so 0 is its behaviour */
     float time;      /* fract(u_time / 120) * 120 */
@@ -221,7 +228,8 @@ typedef struct {
 enum { LAW_NUM = 0, LAW_DIST, LAW_TIME, LAW_ADD, LAW_SUB, LAW_MUL, LAW_DIV, LAW_POW, LAW_GT, LAW_LT, LAW_NEG,
        LAW_CALL1, LAW_CALL2, LAW_CALL3, LAW_UNIFORM, LAW_PX, LAW_PY, LAW_UVX, LAW_UVY };
 enum { LF_SIN = 0, LF_COS, LF_TAN, LF_ABS, LF_SQRT, LF_EXP, LF_LOG, LF_FLOOR, LF_CEIL, LF_FRACT, LF_SIGN,
-       LF_MIN, LF_MAX, LF_POW, LF_STEP, LF_CLAMP, LF_MIX, LF_SMOOTHSTEP, LF_EXP2, LF_LOG2 };
+       LF_MIN, LF_MAX, LF_POW, LF_STEP, LF_CLAMP, LF_MIX, LF_SMOOTHSTEP, LF_EXP2, LF_LOG2,
+       LF_ROUND, LF_MOD, LF_ATAN2, LF_LENGTH2 };
 
 static float law_call(uint32_t fn, float a, float b, float c)
 {
@@ -231,6 +239,10 @@ static float law_call(uint32_t fn, float a, float b, float c)
     case LF_LOG: return gm_log(a); case LF_FLOOR: return gm_floor(a); case LF_CEIL: return -gm_floor(-a);
     case LF_FRACT: return gm_fract(a); case LF_SIGN: return a > 0.0f ? 1.0f : (a < 0.0f ? -1.0f : 0.0f);
     case LF_EXP2: return gm_exp2(a); case LF_LOG2: return gm_log2(a);
+    case LF_ROUND: return rintf(a);                                   /* WGSL round: to nearest, ties to even */
+    case LF_MOD: return a - b * truncf(a * gm_rcp(b));                /* expr.rs:103-109 `%`: truncated remainder, quotient as reciprocal-multiply */
+    case LF_ATAN2: return gm_atan2(a, b);
+    case LF_LENGTH2: return gm_length2(a, b);                         /* length(vec2(a, b)) */
     case LF_MIN: return gm_min(a, b); case LF_MAX: return gm_max(a, b); case LF_POW: return gm_pow(a, b);
     case LF_STEP: return gm_step(a, b);
     case LF_CLAMP: return gm_clamp(a, b, c); case LF_MIX: return gm_mix(a, b, c);
@@ -731,10 +743,25 @@ static void render_rows(const frame_job* J)
         for (uint32_t x = 0; x < J->w; x++) {
             float vx = ((float)x + 0.5f) * inv_w;
             float uvx = vx * 2.0f - 1.0f;
+            float puvy = uvy;
+            if (J->fc.project && J->ir->project_mode == 2) {           /* dome: project.rs:62-69, per pixel */
+                float fov_rad = J->ir->project_fov_deg * 3.14159265359f / 180.0f;
+                float cx = vx - 0.5f, cy = vy - 0.5f;
+                float r = gm_length2(cx, cy) * 2.0f;
+                float theta = gm_atan2(cy, cx);
+                float phi = r * fov_rad * 0.5f;
+                float sp = gm_sin(phi);
+                float wvx = sp * gm_cos(theta) * 0.5f + 0.5f, wvy = sp * gm_sin(theta) * 0.5f + 0.5f;
+                uvx = wvx * 2.0f - 1.0f; puvy = wvy * 2.0f - 1.0f;
+            } else if (J->fc.project && J->ir->project_mode == 4) {    /* led: project.rs:128-137 */
+                float count = (float)J->ir->project_count;
+                float wvx = gm_floor(vx * count) / count;              /* t = f32(led_idx) / f32(count) */
+                uvx = wvx * 2.0f - 1.0f; puvy = 0.5f * 2.0f - 1.0f;
+            }
             size_t idx = (size_t)(ty - J->band_row0) * J->w + x;
             uint32_t prev = J->prev ? J->prev[idx] : 0u;
             float c[4];
-            shade_pixel(J->ir, &J->fc, uvx, uvy, prev, c);
+            shade_pixel(J->ir, &J->fc, uvx, puvy, prev, c);
             J->out[idx] = pack_unorm8(c[0]) | (pack_unorm8(c[1]) << 8) | (pack_unorm8(c[2]) << 16) | (pack_unorm8(c[3]) << 24);
         }
     }
@@ -777,6 +804,7 @@ int game_oracle_render_ex2(const void* blob, size_t blob_len, uint32_t w, uint32
     frame_consts fc;
     fc.wgsl = (semantics & 1) != 0;
     fc.lens_post = (semantics & 4) != 0;
+    fc.project = (semantics & 8) != 0;
     fc.animate = (semantics & 2) != 0 || derived != NULL;
     fc.row = uniforms;
     fc.derived = derived;

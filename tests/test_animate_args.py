@@ -161,8 +161,8 @@ def test_pixel_expressions_are_kept_apart_from_frame_expressions(game):
     assert ir["pixel_exprs"][0] == "(p.x * 0.500000)" and ir["pixel_exprs"][-1] == "(knob * ((1.000000 - (p.x * p.x))))"
     args = [a for l in ir["layers"] for st in l["stages"] for a in st["args"]]
     assert [a["pixel"] for a in args if a["pixel"] >= 0] == list(range(7))
-    # things that are not scalars of the pixel stay defaults: the vector itself, unknown fields
-    for src in ('circle(p * 2.0)', 'circle(p.z)', 'circle(length(p))'):
+    # things that are not scalars of the pixel stay defaults: a vector-valued argument, unknown fields
+    for src in ('circle(p * 2.0)', 'circle(p.z)', 'circle(normalize(p))', 'circle([0.1, 0.2])', 'circle(p > uv)'):
         c = game.compile('cinematic "a" { layer x { fn: %s | glow(1.0) } }' % src).cinematics[0]
         assert c.pixel_expr_count == 0 and c.derived_count == 0
 
@@ -204,3 +204,62 @@ def test_gpu_pixel_expressions_match_oracle(game, oracle, semantics):
     got = r.render(rows)
     r.close()
     assert np.array_equal(got, oracle.render_sequence(cin.blob, w, h, rows, True, semantics=semantics))
+
+
+# ── vector-valued subexpressions (expr.rs:50-144 words them as WGSL vec2f arithmetic) ──────────────────────────────
+VEC = '''cinematic "vec" {
+  layer a {
+    fn: rotate(atan2(p.y, p.x) * 0.1) | circle(0.05 + 0.1 * length(p * 2.0 - [0.5, 0.25])) | glow(1.0 + dot(normalize(p), [0.6, 0.8]) * 0.5)
+        | tint(length(uv) * 0.7, distance(uv, [0.25, -0.5]) * 0.5, 0.5 + 0.5 * sin(dot(uv, uv * 3.0) + time))
+  }
+  layer b {
+    fn: translate(mod(p.x * 3.0, 0.4) - 0.2, round(p.y * 4.0) * 0.1) | ring(0.2 + 0.02 * length(-p), 0.03) | glow(1.5)
+        | tint(min(abs(p), [0.9, 0.8]) * 1.2 - p * 0.0 + [0.1, 0.2] - [0.1, 0.2] > 0.5, 0.4, 0.9)
+  }
+}'''
+
+
+def test_vector_subexpressions_lower_to_scalar_programs(game):
+    cin = game.compile(VEC).cinematics[0]
+    ir = cin.ir
+    # the vec2 > scalar comparison in the last tint has no scalar meaning: that one argument keeps its default
+    assert cin.pixel_expr_count == 9 and cin.derived_count == 0
+    assert ir["pixel_exprs"][1] == "(0.050000 + (0.100000 * length(((p * 2.000000) - [0.500000, 0.250000]))))"
+    # dot(p, [a, b]) is p.x * a + p.y * b, operator for operator
+    a = game.compile('cinematic "a" { layer x { fn: circle(dot(p, [0.5, 0.25])) | glow(1.0) } }').cinematics[0]
+    b = game.compile('cinematic "a" { layer x { fn: circle(p.x * 0.5 + p.y * 0.25) | glow(1.0) } }').cinematics[0]
+    assert a.blob[a.blob.index(b"GIR1") + 8:] == b.blob[b.blob.index(b"GIR1") + 8:]
+
+
+def test_oracle_vector_expressions_follow_their_definitions(game, oracle):
+    """length(v) = sqrt(fma(x, x, y * y)), distance(a, b) = length(a - b), dot = x1 * x2 + y1 * y2, one rounding each."""
+    from np_restatement import F, fma, pack, pixel_grid
+    src = 'cinematic "a" { layer x { fn: gradient() | tint(length(uv) * 0.5, distance(uv, [0.25, -0.5]) * 0.5, dot(uv, uv * 0.5)) } }'
+    cin = game.compile(src).cinematics[0]
+    w, h = 53, 31
+    got = oracle.render(cin.blob, w, h, cin.uniform_rows([0.0], w, h)[0], animate=True)
+    uvx, uvy = pixel_grid(w, h)
+    t = uvy * F(0.5) + F(0.5)
+    r = np.sqrt(fma(uvx, uvx, uvy * uvy)) * F(0.5)
+    dx, dy = uvx - F(0.25), uvy - F(-0.5)
+    g = np.sqrt(fma(dx, dx, dy * dy)) * F(0.5)
+    b = uvx * (uvx * F(0.5)) + uvy * (uvy * F(0.5))
+    assert np.array_equal(got, pack(t * r, t * g, t * b, 1.0))
+
+
+def test_vector_expression_kernels_compile_for_gfx950(game):
+    cin = game.compile(VEC).cinematics[0]
+    assert cin.compile_only(animate=True) > 0 and cin.compile_only(semantics="wgsl", animate=True) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("semantics", ["glsl", "wgsl"])
+def test_gpu_vector_expressions_match_oracle(game, oracle, semantics):
+    cin = game.compile(VEC).cinematics[0]
+    w, h = 160, 90
+    rows = cin.uniform_rows([k / 7 for k in range(3)], w, h)
+    r = cin.renderer(w, h, semantics=semantics, animate=True)
+    got = r.render(rows)
+    r.close()
+    want = oracle.render_sequence(cin.blob, w, h, rows, False, semantics=semantics, animate=True)
+    assert np.array_equal(got, want)
