@@ -43,6 +43,12 @@ typedef struct {
     float damping; uint32_t bounds; char name[64];
 } ir_header;
 
+enum { LAW_NUM = 0, LAW_DIST, LAW_TIME, LAW_ADD, LAW_SUB, LAW_MUL, LAW_DIV, LAW_POW, LAW_GT, LAW_LT, LAW_NEG,
+       LAW_CALL1, LAW_CALL2, LAW_CALL3, LAW_UNIFORM, LAW_PX, LAW_PY, LAW_UVX, LAW_UVY };
+enum { LF_SIN = 0, LF_COS, LF_TAN, LF_ABS, LF_SQRT, LF_EXP, LF_LOG, LF_FLOOR, LF_CEIL, LF_FRACT, LF_SIGN,
+       LF_MIN, LF_MAX, LF_POW, LF_STEP, LF_CLAMP, LF_MIX, LF_SMOOTHSTEP, LF_EXP2, LF_LOG2,
+       LF_ROUND, LF_MOD, LF_ATAN2, LF_LENGTH2 };
+
 #define MAX_PIXEL_EXPRS 256
 typedef struct {
     const ir_header* h;
@@ -57,11 +63,64 @@ typedef struct {
     uint32_t project_count;
 } ir_view;
 
+/* A reverse Polish program is well formed when every operation is known, finds its operands on the stack, the stack
+ * stays within the evaluator's 64 slots and one value is left; `frame_floats` = floats of a frame row it may read
+ * (0: it may read none, as a gravity force law). */
+static int prog_ok(const ir_law* prog, uint32_t n, uint32_t frame_floats, int pixel)
+{
+    int sp = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const ir_law* o = &prog[i];
+        int need = 0, push = 1;
+        switch (o->op) {
+        case LAW_NUM: case LAW_DIST: case LAW_TIME: break;
+        case LAW_UNIFORM: if (o->fn >= frame_floats) return 0; break;
+        case LAW_PX: case LAW_PY: case LAW_UVX: case LAW_UVY: if (!pixel) return 0; break;
+        case LAW_ADD: case LAW_SUB: case LAW_MUL: case LAW_DIV: case LAW_POW: case LAW_GT: case LAW_LT: need = 2; break;
+        case LAW_NEG: need = 1; break;
+        case LAW_CALL1: need = 1; if (o->fn > LF_LENGTH2) return 0; break;
+        case LAW_CALL2: need = 2; if (o->fn > LF_LENGTH2) return 0; break;
+        case LAW_CALL3: need = 3; if (o->fn > LF_LENGTH2) return 0; break;
+        default: return 0;
+        }
+        if (sp < need) return 0;
+        sp = sp - need + push;
+        if (sp > 60) return 0;
+    }
+    return n == 0 || sp >= 1;
+}
+
+/* Everything the interpreter indexes with a value read from the blob is checked here, once, so that a damaged or
+ * hostile blob is refused instead of read out of bounds. */
+static int ir_validate(const ir_view* v)
+{
+    const ir_header* h = v->h;
+    if (h->bounds > 2) return -1;
+    for (uint32_t i = 0; i < h->n_layers; i++) {
+        const ir_layer* L = &v->layers[i];
+        if ((uint64_t)L->stage_begin + L->stage_count > h->n_stages || L->end_state > 2) return -1;
+    }
+    for (uint32_t i = 0; i < h->n_stages; i++) {
+        const ir_stage* S = &v->stages[i];
+        if (S->builtin > B_PALETTE || S->nargs > 4) return -1;
+        for (int k = 0; k < 4; k++) {
+            const ir_arg* a = &S->args[k];
+            if (a->kind > 2 || (a->kind == 1 && a->slot >= h->n_uniforms) || (a->kind == 2 && a->slot >= BU_COUNT)) return -1;
+            if ((a->pad >> 16) > v->n_pix) return -1;
+        }
+    }
+    if (!prog_ok(v->law, h->n_law, 0, 0)) return -1;
+    for (uint32_t i = 0; i < v->n_pix; i++)
+        if (!prog_ok(v->pix[i], v->pix_len[i], BU_COUNT + h->n_uniforms, 1)) return -1;
+    return 0;
+}
+
 static int ir_open(const void* blob, size_t len, ir_view* v)
 {
     if (len < sizeof(ir_header)) return -1;
     const ir_header* h = (const ir_header*)blob;
     if (h->magic != 0x31524947u || h->total != len) return -1;
+    if (h->n_layers > 4096 || h->n_stages > 65536 || h->n_uniforms > 4096 || h->n_law > 4096) return -1;   /* also keeps the sum from wrapping */
     size_t need = sizeof(ir_header) + (size_t)h->n_layers * sizeof(ir_layer) + (size_t)h->n_stages * sizeof(ir_stage) +
                   (size_t)h->n_uniforms * 64 + (size_t)h->n_law * sizeof(ir_law);
     if (need + 4 > len) return -1;
@@ -85,7 +144,7 @@ static int ir_open(const void* blob, size_t len, ir_view* v)
     if (p + 16 != end) return -1;
     memcpy(&v->project_mode, p, 4); memcpy(&v->project_fov_deg, p + 4, 4); memcpy(&v->project_count, p + 8, 4);
     if (v->project_mode > 4) return -1;
-    return 0;
+    return ir_validate(v);
 }
 
 /* ── noise helpers ─────────────────────────────────────────────────────────────────────── */
@@ -224,12 +283,6 @@ typedef struct {
     int animate;     /* expression-valued arguments are live: frame-level ones read `derived`, those that also
                         read the pixel are evaluated here, in f32, where the stage runs */
 } frame_consts;
-
-enum { LAW_NUM = 0, LAW_DIST, LAW_TIME, LAW_ADD, LAW_SUB, LAW_MUL, LAW_DIV, LAW_POW, LAW_GT, LAW_LT, LAW_NEG,
-       LAW_CALL1, LAW_CALL2, LAW_CALL3, LAW_UNIFORM, LAW_PX, LAW_PY, LAW_UVX, LAW_UVY };
-enum { LF_SIN = 0, LF_COS, LF_TAN, LF_ABS, LF_SQRT, LF_EXP, LF_LOG, LF_FLOOR, LF_CEIL, LF_FRACT, LF_SIGN,
-       LF_MIN, LF_MAX, LF_POW, LF_STEP, LF_CLAMP, LF_MIX, LF_SMOOTHSTEP, LF_EXP2, LF_LOG2,
-       LF_ROUND, LF_MOD, LF_ATAN2, LF_LENGTH2 };
 
 static float law_call(uint32_t fn, float a, float b, float c)
 {
