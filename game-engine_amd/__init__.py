@@ -91,6 +91,10 @@ def _load():
         "game_hip_render_into": (c.c_int, [vp, vp, u32, vp]),
         "game_hip_host_alloc": (vp, [sz]),
         "game_hip_host_free": (None, [vp]),
+        "game_hip_set_blur": (c.c_int, [vp, u32]),
+        "game_hip_render_raw_band": (c.c_int, [vp, vp, u32, u32]),
+        "game_hip_raw_rows": (vp, [vp, u32]),
+        "game_hip_blur_band": (c.c_int, [vp, u32, u32, vp]),
         "game_hip_reset_memory": (c.c_int, [vp]),
         "game_hip_set_memory": (c.c_int, [vp, vp, u32, u32]),
         "game_hip_particles_set_time": (c.c_int, [vp, c.c_float]),
@@ -451,6 +455,26 @@ class Renderer:
         out = np.empty((rows.shape[0], nrows, self.w, 4), dtype=np.uint8) if readback else None
         _check(lib.game_hip_render_band(self._h, rows.ctypes.data, rows.shape[0], row0, nrows,
                                         out.ctypes.data if readback else None))
+        return out
+
+    def set_blur(self, radius):
+        """Frame filter: separable binomial blur of radius 1..4 on every frame before it is stored (0 = off)."""
+        _check(lib.game_hip_set_blur(self._h, radius))
+
+    def render_raw_band(self, row, row0, nrows):
+        """Phase one of a band with the frame filter on: one frame's band into the raw frame."""
+        row = self._rows(row)
+        assert row.shape[0] == 1
+        _check(lib.game_hip_render_raw_band(self._h, row.ctypes.data, row0, nrows))
+
+    def raw_rows_ptr(self, row):
+        """Device pointer of a row of the raw frame (for halo exchange between bands)."""
+        return lib.game_hip_raw_rows(self._h, row)
+
+    def blur_band(self, row0, nrows, readback=True):
+        """Phase two: blur the band (reading its halo rows in the raw frame) into the next ring slot."""
+        out = np.empty((nrows, self.w, 4), dtype=np.uint8) if readback else None
+        _check(lib.game_hip_blur_band(self._h, row0, nrows, out.ctypes.data if readback else None))
         return out
 
     def reset_memory(self):

@@ -7,6 +7,7 @@
 #include "../front/capi_internal.hpp"
 #include "codegen.hpp"
 #include "scratch.hpp"
+#include "blur.hpp"
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 #include <chrono>
@@ -70,6 +71,10 @@ struct game_hip_ctx {
     float* vy = nullptr;
     int cur = 0;
     float sim_time = 0.0f;
+    // frame filter (game_hip_set_blur): the fused kernel renders into `raw`, the blur writes the ring slot
+    uint32_t blur = 0;
+    uint32_t* raw = nullptr;
+    bool raw_pending = false;   // game_hip_render_raw_band ran and game_hip_blur_band has not consumed it yet
     float compile_ms = 0.0f, tables_ms = 0.0f;   // host time game_hip_create spent in hiprtc / building lattice tables
     // game_hip_render_into: this device's static scratch array (not owned), a page-locked staging buffer of the same
     // size made at creation, and the event that says the last copy out of the staging buffer has finished
@@ -372,7 +377,24 @@ int render_impl(game_hip_ctx* c, const float* uniforms, uint32_t nframes, uint32
     if (rc) return rc;
     CallEvents events(c);
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    if (c->ir.uses_memory) {
+    if (c->blur) {
+        // frame by frame: fused kernel -> raw frame, blur -> ring slot; a memory cinematic reads the blurred slot of the
+        // frame before. Rows of `raw` outside the band are read as they are (the caller's halo rows).
+        for (uint32_t f = 0; f < nframes; ++f) {
+            uint32_t slot = c->next_slot;
+            const uint32_t* prev = c->ir.uses_memory && c->last_slot >= 0 ? c->frames + (size_t)c->last_slot * frame_px : nullptr;
+            rc = launch_frames_into(c, c->raw, 1, c->utab_dev, f, 1, 0, prev, row0, rows);
+            if (rc) return rc;
+            rc = launch_blur(c->raw, c->frames + (size_t)slot * frame_px, c->w, c->h, row0, rows, c->blur, c->stream);
+            if (rc) return rc;
+            c->last_launches += 2;
+            if (host)
+                HIP_TRY(hipMemcpyAsync(host + (size_t)f * band_bytes, c->frames + (size_t)slot * frame_px + (size_t)row0 * c->w,
+                                       band_bytes, hipMemcpyDeviceToHost, c->stream));
+            c->last_slot = (int)slot;
+            c->next_slot = (slot + 1) % c->ring;
+        }
+    } else if (c->ir.uses_memory) {
         // frame-serial: frame k reads the slot frame k-1 was written to
         for (uint32_t f = 0; f < nframes; ++f) {
             uint32_t slot = c->next_slot;
@@ -560,6 +582,7 @@ void game_hip_destroy(game_hip_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->frames) (void)hipFree(c->frames);
+    if (c->raw) (void)hipFree(c->raw);
     if (c->utab_dev) (void)hipFree(c->utab_dev);
     for (int i = 0; i < 2; ++i) {
         if (c->px[i]) (void)hipFree(c->px[i]);
@@ -646,6 +669,67 @@ int game_hip_render_into(game_hip_ctx* c, const float* uniforms, uint32_t nframe
         ++c->last_launches;
     }
     if (timed) { HIP_TRY(hipEventRecord(c->ev_own1, c->stream)); c->own_recorded = true; }
+    return GAME_OK;
+}
+
+int game_hip_set_blur(game_hip_ctx* c, uint32_t radius)
+{
+    if (!c) return set_error(GAME_E_ARGUMENT, "game_hip_set_blur: null context");
+    if (radius > 4) return set_error(GAME_E_ARGUMENT, "game_hip_set_blur: radius must be 0 (off) to 4");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (radius && !c->raw) {
+        const size_t bytes = (size_t)c->w * c->h * 4;
+        HIP_TRY(hipMalloc((void**)&c->raw, bytes));
+        HIP_TRY(hipMemsetAsync(c->raw, 0, bytes, c->stream));
+    }
+    if (!radius && c->raw) { HIP_TRY(hipFree(c->raw)); c->raw = nullptr; }
+    c->blur = radius;
+    c->raw_pending = false;
+    return GAME_OK;
+}
+
+int game_hip_render_raw_band(game_hip_ctx* c, const float* uniforms, uint32_t row0, uint32_t rows)
+{
+    if (!c || !uniforms) return set_error(GAME_E_ARGUMENT, "game_hip_render_raw_band: null argument");
+    if (!c->blur || !c->raw) return set_error(GAME_E_UNSUPPORTED, "game_hip_render_raw_band: no frame filter is set (game_hip_set_blur)");
+    if (rows == 0 || (uint64_t)row0 + rows > c->h) return set_error(GAME_E_ARGUMENT, "game_hip_render_raw_band: band outside the image");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = upload_rows(c, uniforms, 1);
+    if (rc) return rc;
+    const size_t frame_px = (size_t)c->w * c->h;
+    const uint32_t* prev = c->ir.uses_memory && c->last_slot >= 0 ? c->frames + (size_t)c->last_slot * frame_px : nullptr;
+    rc = launch_frames_into(c, c->raw, 1, c->utab_dev, 0, 1, 0, prev, row0, rows);
+    if (rc) return rc;
+    c->raw_pending = true;
+    return GAME_OK;
+}
+
+void* game_hip_raw_rows(game_hip_ctx* c, uint32_t row)
+{
+    if (!c || !c->raw || row >= c->h) return nullptr;
+    return c->raw + (size_t)row * c->w;
+}
+
+int game_hip_blur_band(game_hip_ctx* c, uint32_t row0, uint32_t rows, uint8_t* rgba8_host)
+{
+    if (!c) return set_error(GAME_E_ARGUMENT, "game_hip_blur_band: null context");
+    if (!c->blur || !c->raw_pending) return set_error(GAME_E_UNSUPPORTED, "game_hip_blur_band: no raw band is waiting (game_hip_render_raw_band)");
+    if (rows == 0 || (uint64_t)row0 + rows > c->h) return set_error(GAME_E_ARGUMENT, "game_hip_blur_band: band outside the image");
+    if (!c->frames || c->ring == 0) return set_error(GAME_E_HIP, "game_hip_blur_band: the frame ring is not allocated");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t frame_px = (size_t)c->w * c->h;
+    const uint32_t slot = c->next_slot;
+    int rc = launch_blur(c->raw, c->frames + (size_t)slot * frame_px, c->w, c->h, row0, rows, c->blur, c->stream);
+    if (rc) return rc;
+    c->raw_pending = false;
+    c->last_slot = (int)slot;
+    c->next_slot = (slot + 1) % c->ring;
+    if (rgba8_host) {
+        HIP_TRY(hipMemcpyAsync(rgba8_host, c->frames + (size_t)slot * frame_px + (size_t)row0 * c->w, (size_t)rows * c->w * 4,
+                               hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     return GAME_OK;
 }
 

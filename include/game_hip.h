@@ -242,6 +242,25 @@ int game_hip_render_into(game_hip_ctx* ctx, const float* uniforms, uint32_t nfra
  * pointer is accepted by the render calls; this pair is a convenience around hipHostMalloc / hipHostFree. */
 void* game_hip_host_alloc(size_t bytes);
 void game_hip_host_free(void* p);
+/* Frame filter (an extension: the reference's post passes are all pointwise, game-compiler/src/codegen/glsl.rs:440-505,
+ * and it has no blur). radius 1..4 turns on a separable binomial blur of every rendered frame before it is stored
+ * in the ring - and so before it becomes the next frame's memory: weights C(2r, k), each pass
+ * (sum of weight * byte + 4^r / 2) >> 2r per channel, coordinates clamped to the frame (the memory texture of
+ * memory.rs:114-115 is CLAMP_TO_EDGE); radius 0 turns it off. With the filter on, frames are rendered one launch pair at
+ * a time (fused kernel into a raw frame, blur into the ring slot).
+ * Band sharding with the filter needs `radius` halo rows from the neighbouring bands, and they must be the neighbours'
+ * RAW rows of the same frame. The two-phase calls leave room for that exchange, device to device:
+ *   game_hip_render_raw_band  renders one frame's band into the raw frame (does not advance the ring);
+ *   game_hip_raw_rows         device pointer of row `row` of the raw frame (w RGBA8 words per row): send the band's
+ *                             first / last `radius` rows to the ranks above / below and receive theirs into the rows
+ *                             just outside the band (RCCL send/recv, or a peer copy), queued on game_hip_stream;
+ *   game_hip_blur_band        blurs the band into the next ring slot (reading the halo rows) and advances the ring.
+ * game_hip_render / _render_band with the filter on do both phases back to back and read whatever the raw frame
+ * holds outside the band. */
+int game_hip_set_blur(game_hip_ctx* ctx, uint32_t radius);
+int game_hip_render_raw_band(game_hip_ctx* ctx, const float* uniforms /* one row */, uint32_t row0, uint32_t rows);
+void* game_hip_raw_rows(game_hip_ctx* ctx, uint32_t row);
+int game_hip_blur_band(game_hip_ctx* ctx, uint32_t row0, uint32_t rows, uint8_t* rgba8_host /* band or NULL */);
 int game_hip_reset_memory(game_hip_ctx* ctx);          /* previous-frame store := 0 */
 /* Checkpoint / resume of the feedback state (the reference keeps it in a browser texture and has no such call):
  * loads rows [row0, row0 + rows) of an RGBA8 frame, top row first - typically the last frame (or band) a previous

@@ -213,3 +213,20 @@ def render_wgsl_post_chain(w, h):
         x = x * F(1.2)
         return clamp((x * (F(2.51) * x + F(0.03))) / (x * (F(2.43) * x + F(0.59)) + F(0.14)), 0.0, 1.0)
     return pack(aces(r), aces(g), aces(b), 1.0)
+
+
+def blur_rgba8(frame, radius):
+    """The frame filter of game_hip_set_blur on an (h, w, 4) uint8 frame: binomial weights C(2r, k), horizontal pass
+    then vertical pass, each (sum of weight * byte + 4^r / 2) >> 2r per channel with coordinates clamped to the frame."""
+    from math import comb
+    wts = [comb(2 * radius, k) for k in range(2 * radius + 1)]
+
+    def one_pass(a, axis):
+        n = a.shape[axis]
+        acc = np.zeros(a.shape, dtype=np.uint32)
+        for k, wk in enumerate(wts):
+            idx = np.clip(np.arange(n) + k - radius, 0, n - 1)
+            acc += np.uint32(wk) * np.take(a, idx, axis=axis).astype(np.uint32)
+        return ((acc + np.uint32(1 << (2 * radius - 1))) >> np.uint32(2 * radius)).astype(np.uint8)
+
+    return one_pass(one_pass(frame, 1), 0)
