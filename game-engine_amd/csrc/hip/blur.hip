@@ -5,9 +5,12 @@
 // row C(2r, k) (sum 4^r); the horizontal pass replaces every channel by (sum of weight * byte + 4^r / 2) >> 2r with
 // x clamped to the frame, the vertical pass does the same over y with the horizontal results (themselves bytes).
 //
-// A workgroup of 256 lanes owns a 64 x 32 pixel tile: it loads the tile plus r pixels all round into LDS (one coalesced
-// RGBA8 word per lane per step), runs the horizontal pass over 32 + 2r rows into a second LDS array, then the vertical
-// pass, and stores one word per lane per step. Both passes handle two channels per 32-bit operation: R and B sit in
+// A workgroup of 256 lanes owns a 64 x 64 pixel tile: it loads the tile plus four pixels left and right and r rows above
+// and below into LDS as 16-byte words (all of a lane's loads in flight together), runs the horizontal pass over
+// 64 + 2r rows into a second LDS array, then the vertical pass, in which every lane makes a 4 x 4 block and stores it as
+// four 16-byte words. In both passes four adjacent outputs come from one run of 4 + 2r samples, so every sample is read
+// from LDS and split into channels once per four outputs. Frames whose width is not a multiple of 4 take the same
+// kernel with 4-byte global accesses. Both passes handle two channels per 32-bit operation: R and B sit in
 // the two 16-bit halves of (p & 0x00ff00ff), G and A in those of ((p >> 8) & 0x00ff00ff), and since the weights sum to
 // at most 256 a 16-bit half never overflows (255 * 256 + 128 < 65536). HBM traffic is one read and one write of the
 // frame (halo pixels are shared between neighbouring tiles through L2).
@@ -17,7 +20,8 @@
 
 namespace {
 
-constexpr uint32_t TX = 64, TY = 32;
+constexpr uint32_t TX = 64, TY = 64;
+constexpr int VB = (int)(TY / 16u);   // rows of the block a lane makes in the vertical pass
 
 template <int R>
 struct Binomial;
@@ -35,49 +39,102 @@ __device__ __forceinline__ uint32_t finish(uint32_t rb, uint32_t ga)
     return rb | (ga << 8);
 }
 
-template <int R>
+// One pass over a run of consecutive samples p[OFF .. OFF + 4 + 2R): four adjacent outputs. Every sample is split into
+// its two channel pairs once; the weights are symmetric, so the two samples at distance d from an output's centre are
+// added before they are weighted (an add is cheaper than an integer multiply-add here).
+template <int R, int OFF, int N = 4>
+__device__ __forceinline__ void four_outputs(const uint32_t (&p)[12], uint32_t (&o)[N])
+{
+    uint32_t rb[N + 2 * R], ga[N + 2 * R];
+#pragma unroll
+    for (int i = 0; i < N + 2 * R; ++i) { rb[i] = p[OFF + i] & 0x00ff00ffu; ga[i] = (p[OFF + i] >> 8) & 0x00ff00ffu; }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        uint32_t arb = Binomial<R>::w[R] * rb[j + R], aga = Binomial<R>::w[R] * ga[j + R];
+#pragma unroll
+        for (int d = 1; d <= R; ++d) {
+            arb += Binomial<R>::w[R - d] * (rb[j + R - d] + rb[j + R + d]);
+            aga += Binomial<R>::w[R - d] * (ga[j + R - d] + ga[j + R + d]);
+        }
+        o[j] = finish<R>(arb, aga);
+    }
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// VEC: the frame's rows are 16-byte aligned (width a multiple of 4), so the tile moves as 16-byte words.
+template <int R, bool VEC>
 __global__ __launch_bounds__(256) void blur_kernel(const uint32_t* __restrict__ raw, uint32_t* __restrict__ out, uint32_t w, uint32_t h,
                                                    uint32_t row0, uint32_t rows)
 {
-    constexpr uint32_t IW = TX + 2 * R, IH = TY + 2 * R;
-    __shared__ uint32_t in[IH][IW];
-    __shared__ uint32_t mid[IH][TX];
+    constexpr uint32_t IH = TY + 2 * R;
+    constexpr uint32_t CH = TX / 4u + 2u;                 // 16-byte chunks per tile row: the tile and four pixels either side
+    constexpr uint32_t IWP = CH * 4u;
+    __shared__ __attribute__((aligned(16))) uint32_t in[IH][IWP];   // column 0 = frame column x0 - 4
+    __shared__ __attribute__((aligned(16))) uint32_t mid[IH][TX];
     const uint32_t tid = threadIdx.x;
     const int x0 = (int)(blockIdx.x * TX), y0 = (int)(row0 + blockIdx.y * TY);
-    for (uint32_t i = tid; i < IW * IH; i += 256u) {
-        const uint32_t ly = i / IW, lx = i - ly * IW;
-        int gx = x0 - R + (int)lx, gy = y0 - R + (int)ly;
-        gx = gx < 0 ? 0 : (gx >= (int)w ? (int)w - 1 : gx);     // clamp to the frame's edge
-        gy = gy < 0 ? 0 : (gy >= (int)h ? (int)h - 1 : gy);
-        in[ly][lx] = raw[(size_t)gy * w + (uint32_t)gx];
+    // all loads of the lane are issued before the first one is waited for (a fixed, unrolled count)
+    constexpr uint32_t NLOAD = (CH * IH + 255u) / 256u;
+    u32x4 held[NLOAD];
+#pragma unroll
+    for (uint32_t k = 0; k < NLOAD; ++k) {
+        const uint32_t i = tid + 256u * k;
+        const uint32_t ly = i / CH, c = i - ly * CH;
+        int gy = y0 - R + (int)ly;
+        gy = gy < 0 ? 0 : (gy >= (int)h ? (int)h - 1 : gy);       // clamp to the frame's edge (also keeps idle lanes in range)
+        const int gx = x0 - 4 + 4 * (int)c;
+        const uint32_t* row = raw + (size_t)(uint32_t)gy * w;
+        if (VEC && gx >= 0 && gx + 3 < (int)w) held[k] = *(const u32x4*)(row + gx);
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int x = gx + e;
+                x = x < 0 ? 0 : (x >= (int)w ? (int)w - 1 : x);
+                held[k][e] = row[x];
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < NLOAD; ++k) {
+        const uint32_t i = tid + 256u * k;
+        const uint32_t ly = i / CH, c = i - ly * CH;
+        if (i < CH * IH) *(u32x4*)&in[ly][4u * c] = held[k];
     }
     __syncthreads();
-    for (uint32_t i = tid; i < TX * IH; i += 256u) {
-        const uint32_t y = i / TX, x = i % TX;
-        uint32_t rb = 0, ga = 0;
+    // horizontal pass: a lane makes four adjacent pixels of one row from twelve consecutive words (three 16-byte reads)
+    for (uint32_t i = tid; i < (TX / 4u) * IH; i += 256u) {
+        const uint32_t y = i / (TX / 4u), x = (i % (TX / 4u)) * 4u;
+        uint32_t p[12], o[4];
+        const u32x4* src = (const u32x4*)&in[y][x];
 #pragma unroll
-        for (int k = 0; k <= 2 * R; ++k) {
-            const uint32_t p = in[y][x + (uint32_t)k];
-            rb += Binomial<R>::w[k] * (p & 0x00ff00ffu);
-            ga += Binomial<R>::w[k] * ((p >> 8) & 0x00ff00ffu);
-        }
-        mid[y][x] = finish<R>(rb, ga);
+        for (int v = 0; v < 3; ++v) { const u32x4 q = src[v]; p[4 * v] = q[0]; p[4 * v + 1] = q[1]; p[4 * v + 2] = q[2]; p[4 * v + 3] = q[3]; }
+        four_outputs<R, 4 - R>(p, o);                     // output x of the tile is centred on word x + 4 of `in`
+        *(u32x4*)&mid[y][x] = u32x4{o[0], o[1], o[2], o[3]};
     }
     __syncthreads();
-    const uint32_t x = tid % TX;
-    const uint32_t gx = (uint32_t)x0 + x;
+    // vertical pass: a lane makes a block of 4 x VB pixels from VB + 2R rows of four words
+    static_assert(TX / 4u * (TY / (uint32_t)VB) == 256u, "one block per lane");
+    const uint32_t bx = (tid % (TX / 4u)) * 4u, by = (tid / (TX / 4u)) * (uint32_t)VB;
+    uint32_t col[4][12] = {}, o[4][VB];
 #pragma unroll
-    for (uint32_t j = 0; j < TY; j += 256u / TX) {
-        const uint32_t y = j + tid / TX;
-        uint32_t rb = 0, ga = 0;
+    for (int k = 0; k < VB + 2 * R; ++k) {
+        const u32x4 q = *(const u32x4*)&mid[by + (uint32_t)k][bx];
+        col[0][k] = q[0]; col[1][k] = q[1]; col[2][k] = q[2]; col[3][k] = q[3];
+    }
 #pragma unroll
-        for (int k = 0; k <= 2 * R; ++k) {
-            const uint32_t p = mid[y + (uint32_t)k][x];
-            rb += Binomial<R>::w[k] * (p & 0x00ff00ffu);
-            ga += Binomial<R>::w[k] * ((p >> 8) & 0x00ff00ffu);
+    for (int c = 0; c < 4; ++c) four_outputs<R, 0, VB>(col[c], o[c]);
+    const uint32_t gx = (uint32_t)x0 + bx;
+#pragma unroll
+    for (uint32_t j = 0; j < (uint32_t)VB; ++j) {
+        const uint32_t gy = (uint32_t)y0 + by + j;
+        if (gy >= row0 + rows) break;
+        uint32_t* dst = out + (size_t)gy * w + gx;
+        if (VEC && gx + 3u < w) *(u32x4*)dst = u32x4{o[0][j], o[1][j], o[2][j], o[3][j]};
+        else {
+#pragma unroll
+            for (uint32_t c = 0; c < 4u; ++c) if (gx + c < w) dst[c] = o[c][j];
         }
-        const uint32_t gy = (uint32_t)y0 + y;
-        if (gx < w && gy < row0 + rows) out[(size_t)gy * w + gx] = finish<R>(rb, ga);
     }
 }
 
@@ -90,12 +147,21 @@ int launch_blur(const uint32_t* raw, uint32_t* out, uint32_t w, uint32_t h, uint
     if (!raw || !out || radius < 1 || radius > 4 || rows == 0 || (uint64_t)row0 + rows > h)
         return set_error(GAME_E_ARGUMENT, "blur: radius must be 1..4 and the band inside the frame");
     const dim3 grid((w + TX - 1) / TX, (rows + TY - 1) / TY), block(256);
+    // 16-byte tile moves need every row (and the two frame pointers) on a 16-byte boundary
+    const bool vec = w % 4u == 0u && ((uintptr_t)raw & 15u) == 0u && ((uintptr_t)out & 15u) == 0u;
+#define GAME_BLUR_CASE(R)                                                                                             \
+    case R:                                                                                                            \
+        if (vec) hipLaunchKernelGGL((blur_kernel<R, true>), grid, block, 0, stream, raw, out, w, h, row0, rows);      \
+        else hipLaunchKernelGGL((blur_kernel<R, false>), grid, block, 0, stream, raw, out, w, h, row0, rows);         \
+        break;
     switch (radius) {
-    case 1: hipLaunchKernelGGL(blur_kernel<1>, grid, block, 0, stream, raw, out, w, h, row0, rows); break;
-    case 2: hipLaunchKernelGGL(blur_kernel<2>, grid, block, 0, stream, raw, out, w, h, row0, rows); break;
-    case 3: hipLaunchKernelGGL(blur_kernel<3>, grid, block, 0, stream, raw, out, w, h, row0, rows); break;
-    default: hipLaunchKernelGGL(blur_kernel<4>, grid, block, 0, stream, raw, out, w, h, row0, rows); break;
+        GAME_BLUR_CASE(1)
+        GAME_BLUR_CASE(2)
+        GAME_BLUR_CASE(3)
+        GAME_BLUR_CASE(4)
+    default: break;
     }
+#undef GAME_BLUR_CASE
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GAME_E_HIP, std::string("blur launch: ") + hipGetErrorString(e));
     return GAME_OK;
