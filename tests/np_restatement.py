@@ -9,6 +9,28 @@ import numpy as np
 
 F = np.float32
 
+# literal_form(): evaluate the reference's wording literally instead - no fused multiply-add anywhere, every quotient a
+# true IEEE division, the framebuffer write round(clamp(c, 0, 1) * 255) half up, the texel fetch byte / 255. The render
+# path deviates from that form where GLSL leaves the choice open (contraction points; reciprocal-multiply quotients,
+# within 1.5 ulp of the division GLSL bounds by 2.5 ulp); tests use this mode to bound what the deviations cost.
+LITERAL = False
+
+
+class literal_form:
+    def __enter__(self):
+        global LITERAL
+        self.saved, LITERAL = LITERAL, True
+
+    def __exit__(self, *exc):
+        global LITERAL
+        LITERAL = self.saved
+
+
+def quotient(x, y):
+    """x / y as the render path defines quotients by a stage argument, a constant or a length: x * (1 / y)."""
+    x, y = f(x), f(y)
+    return x / y if LITERAL else x * (F(1.0) / y)
+
 
 def f(x):
     return np.asarray(x, dtype=np.float32)
@@ -17,6 +39,8 @@ def f(x):
 def fma(a, b, c):
     """Correctly rounded float32 a*b+c: the product is exact in float64, the sum is rounded to odd
     (53 >= 2*24+2 bits), and the final float64 -> float32 conversion rounds once."""
+    if LITERAL:
+        return (f(a) * f(b) + f(c)).astype(np.float32)
     a, b, c = (np.asarray(v, dtype=np.float32).astype(np.float64) for v in (a, b, c))
     a, b, c = np.broadcast_arrays(a, b, c)
     p = a * b
@@ -44,7 +68,7 @@ def clamp(x, lo, hi):
 
 
 def smoothstep(e0, e1, x):
-    t = clamp((x - F(e0)) * (F(1.0) / (F(e1) - F(e0))), 0.0, 1.0)   # one reciprocal, one multiply
+    t = clamp(quotient(x - F(e0), F(e1) - F(e0)), 0.0, 1.0)   # one reciprocal, one multiply
     return t * t * fma(F(-2.0), t, F(3.0))
 
 
@@ -79,14 +103,14 @@ def fbm2(px, py, octaves, persistence, lacunarity):  # glsl.rs:155-169
         amplitude = F(amplitude * F(persistence))
         frequency = F(frequency * F(lacunarity))
         qx, qy = fma(qx, F(0.8), -(qy * F(0.6))), fma(qx, F(0.6), qy * F(0.8))
-    return value * (F(1.0) / max_val)
+    return quotient(value, max_val)
 
 
 def apply_glow(d, intensity):  # glsl.rs:102-107
     i = F(intensity)
     core = smoothstep(0.005, -0.005, d)
     md = np.maximum(d, F(0.0))
-    halo = i * (F(1.0) / fma(md * md * i * i, F(16.0), F(1.0)))   # one reciprocal, one multiply
+    halo = quotient(i, fma(md * md * i * i, F(16.0), F(1.0)))   # one reciprocal, one multiply
     return core + halo
 
 
@@ -102,6 +126,8 @@ def pixel_grid(w, h):
 
 def pack(r, g, b, a):
     def u8(c):
+        if LITERAL:
+            return np.floor(clamp(np.where(np.isnan(c), F(0.0), c), 0.0, 1.0) * F(255.0) + F(0.5)).astype(np.uint32).astype(np.uint8)
         t = np.rint(c * F(255.0))                      # to the nearest integer, ties to even
         t = np.where(np.isnan(t), F(0.0), t)
         return np.minimum(np.maximum(t, F(0.0)), F(255.0)).astype(np.uint32).astype(np.uint8)
@@ -142,7 +168,7 @@ def render_c3_no_grain(w, h, bass, mid, treble):
     add = np.maximum(lum - F(0.4), F(0.0)) * F(2.0)
     r, g, b = r + add, g + add, b + add
     ln = np.sqrt(fma(uvx, uvx, uvy * uvy))
-    dirx = uvx * (F(1.0) / ln) * F(0.6)
+    dirx = quotient(uvx, ln) * F(0.6)
     r, b = r * (F(1.0) + dirx), b * (F(1.0) - dirx)
     fac = F(1.0) - smoothstep(0.8, F(0.8) + F(0.35), ln)
     return pack(r * fac, g * fac, b * fac, 1.0)
@@ -150,7 +176,7 @@ def render_c3_no_grain(w, h, bass, mid, treble):
 
 def memory_mix(cur_rgba_float, prev_rgba8, decay):
     """memory.rs:38-45 on float colours; prev is RGBA8."""
-    prev = prev_rgba8.astype(np.float32) * F(np.float32(1.0) / np.float32(255.0))   # byte times RN(1 / 255)
+    prev = quotient(prev_rgba8.astype(np.float32), F(255.0))   # byte times RN(1 / 255)
     return mix(cur_rgba_float, prev, F(decay))
 
 
@@ -167,9 +193,8 @@ def gravity_step(p, dt, damping, law, bounds, time):
     for j in range(n):
         dx, dy = p[j, 0] - sx, p[j, 1] - sy
         dist = np.maximum(np.sqrt(fma(dx, dx, dy * dy)), F(0.001))
-        inv = F(1.0) / dist
         f = np.broadcast_to(np.asarray(law(dist, F(time)), dtype=np.float32), dist.shape)
-        nfx, nfy = fma(dx * inv, f, fx), fma(dy * inv, f, fy)
+        nfx, nfy = fma(quotient(dx, dist), f, fx), fma(quotient(dy, dist), f, fy)
         keep = idx == j
         fx, fy = np.where(keep, fx, nfx), np.where(keep, fy, nfy)
     vx = p[:, 2] * F(damping) + fx * F(dt)

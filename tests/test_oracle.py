@@ -351,3 +351,61 @@ def test_blocked_gravity_loop_equals_scalar_loop(game, oracle):
         a, ta = oracle.gravity(cin.blob, p, 1 / 60, 3, threads=3)
         b, tb = oracle.gravity(cin.blob, p, 1 / 60, 3, threads=3, blocked=False)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and ta == tb
+
+
+def _psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+def test_deviations_from_the_literal_wording_stay_inside_the_image_tolerance(game, oracle):
+    """Where GLSL leaves the evaluation open the render path picks the cheap form (fused multiply-adds at fixed points,
+    quotients as reciprocal-multiply, the frame store as round-to-nearest-even of c * 255, the texel fetch as
+    byte * RN(1 / 255)). Against the reference's wording taken literally - every operator one IEEE operation, true
+    divisions, round half up - the frames must stay inside the stated bar: at most 1/255 per channel, PSNR >= 50 dB."""
+    w, h = 96, 54
+    cases = []
+    for src, fn, args in ((C1_HELLO, NP.render_c1, (w, h)), (C2_FBM, NP.render_c2, (w, h)),
+                          (C3_SHOWCASE.replace("\n      | grain(0.025)", ""), NP.render_c3_no_grain, (w, h, 0.8, 0.6, 0.4))):
+        cin = game.compile(src).cinematics[0]
+        row = cin.uniform_rows([0.0], w, h, audio={"bass": 0.8, "mid": 0.6, "treble": 0.4})[0]
+        got = oracle.render(cin.blob, w, h, row)
+        with NP.literal_form():
+            lit = fn(*args)
+        cases.append((cin.name, got, lit))
+    # the feedback recurrence over 24 frames: differences must not build up through the re-quantised previous frame
+    cin = game.compile(C4_TRAILS).cinematics[0]
+    n = 24
+    bass = [0.5 + 0.5 * np.sin(2 * np.pi * 0.5 * k / 60) for k in range(n)]
+    rows = cin.uniform_rows([k / 60 for k in range(n)], w, h, audio={"bass": bass})
+    seq = oracle.render_sequence(cin.blob, w, h, rows, True, threads=2)
+    uvx, uvy = NP.pixel_grid(w, h)
+    prev = np.zeros((h, w, 4), dtype=np.uint8)
+    with NP.literal_form():
+        for k in range(n):
+            px, py = uvx * (NP.F(w) / NP.F(h)) - NP.F(bass[k]), uvy - NP.F(0.0)
+            g = NP.apply_glow(np.sqrt(px * px + py * py) - NP.F(0.1), 2.5)
+            cur = np.stack([g * NP.F(1.0), g * NP.F(0.5), g * NP.F(0.2), np.ones_like(g)], axis=-1)
+            mixed = NP.memory_mix(cur, prev, 0.97)
+            prev = NP.pack(mixed[..., 0], mixed[..., 1], mixed[..., 2], mixed[..., 3])
+    cases.append(("trails frame 24", seq[-1], prev))
+    for name, got, lit in cases:
+        ok = ~(np.isnan(lit.astype(np.float32)))            # (uint8: always true; kept for symmetry with the uv = 0 pixel)
+        diff = np.abs(got.astype(np.int16) - lit.astype(np.int16))[ok]
+        assert diff.max() <= 1, (name, int(diff.max()))
+        assert _psnr(got, lit) >= 50.0, (name, _psnr(got, lit))
+
+
+def test_gravity_deviation_from_the_literal_wording(game, oracle):
+    """gravity.rs:82-87 words the pair term as `dir = diff / dist; force = force + dir * f`; the render path multiplies
+    by one correctly rounded reciprocal and accumulates with a fused multiply-add. One step of both forms agrees to
+    1e-5 relative (the bar for 100 steps is 1e-4; over many steps of a chaotic system only bit-identical forms agree)."""
+    cin = game.compile('cinematic "t" { gravity { rule: 0.05 / (dist + 0.2), damping: 0.97, bounds: none } layer s { circle() | glow() } }').cinematics[0]
+    p0 = oracle.seed_particles(300, seed=21)
+    got, _ = oracle.gravity(cin.blob, p0, 1 / 60, 1)
+    law = lambda d, t: NP.F(0.05) / (d + NP.F(0.2))
+    with NP.literal_form():
+        lit = NP.gravity_step(p0, np.float32(1 / 60), 0.97, law, "none", np.float32(1 / 60))
+    rel = np.abs(got - lit) / np.maximum(np.abs(lit), 1e-3)
+    assert rel.max() <= 1e-5, rel.max()
+    assert not np.array_equal(got, lit)
