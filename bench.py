@@ -255,7 +255,7 @@ def time_frames(args, game, torch, rank, world, local, key, steps, warmup, extra
                      "pixels_per_launch": px_launch, "launches_timed": launches})
         out["roofline"] = roof
         out["setup"] = {"context_create_ms": round(create_ms, 1), "kernel_compile_ms": round(compile_ms, 1), "table_build_ms": round(tables_ms, 1)}
-    if rank == 0 and world == 1 and extras:
+    if rank == 0 and world == 1 and extras and not args.no_cpu:   # comparison legs (skipped together: profiler runs)
         if cfg["bound"] == "valu" and not os.environ.get("GAME_HIP_NO_LUT") and "roofline" in out:
             # the same workload with every hash evaluated arithmetically (no tables), a few launches, outside the main timing
             os.environ["GAME_HIP_NO_LUT"] = "1"
@@ -281,7 +281,7 @@ def time_frames(args, game, torch, rank, world, local, key, steps, warmup, extra
             r.render(table[:nf], out=host)
             out["pcie_inclusive_mpixel_s"] = round(nf * w * h / (time.perf_counter() - t1) / 1e6, 1)
             del host
-        if not args.no_cpu:
+        if True:
             oracle = load_oracle()
             out["cpu_baseline"] = cpu_baseline_frames(oracle, cin, cfg, table, args.cpu_seconds)
             # parity spot check outside the timed region: a band of the last frame against the oracle
@@ -377,7 +377,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per launch; default 25 (200 for the 1024x1024 config)")
     ap.add_argument("--particles", type=int, default=1048576)
     ap.add_argument("--no-events", dest="events", action="store_false", help="skip per-step HIP event timing")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the comparison legs (CPU baseline, table-free build, host delivery)")
     ap.add_argument("--no-others", action="store_true", help="skip the brief runs of the other configs after the headline")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()

@@ -13,10 +13,16 @@ out = {}
 for c in configs:
     d = json.load(open(f"profiles/{rnd}_{c}.json"))
     kname = "game_gravity" if c == "c5" else "game_frame"
-    k = [v for kk, v in d["pmc_per_dispatch"].items() if kk.startswith(kname)][0]
-    res = [r for r in d["kernel_resources"] if r["name"] == kname][0]
+    # the launch shape the run is made of: the one with the most dispatches (comparison legs add a few others)
+    res = max((r for r in d["kernel_resources"] if r["name"] == kname), key=lambda r: r["dispatches"])
+    k = max((v for kk, v in d["pmc_per_dispatch"].items() if kk.startswith(kname)), key=lambda v: v["SQ_WAVES"]["dispatches"])
     fetch, write = k["FETCH_SIZE"]["avg"] * 1024, k["WRITE_SIZE"]["avg"] * 1024
-    out[c] = {"kernel": kname, "frames_per_launch": res["grid"][2], "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
+    line = d["bench_lines"]["trace_stdout.txt"]
+    # what bench.py matches a record by: the launch shape (frames per launch; particles for the gravity kernel) and the
+    # hash of the kernel build the counters were taken on
+    shape = line["config"]["particles"] if c == "c5" else res["grid"][2]
+    out[c] = {"kernel": kname, "frames_per_launch": shape, "kernel_hash": line["roofline"]["kernel_hash"],
+              "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
               "fetch_correction": 2.0, "traffic_bytes_per_launch": 2.0 * fetch + write,
               "waves_per_launch": k["SQ_WAVES"]["avg"],
               "valu_instructions_per_wave": k["SQ_INSTS_VALU"]["avg"] / k["SQ_WAVES"]["avg"],
