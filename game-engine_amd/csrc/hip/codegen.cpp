@@ -208,8 +208,17 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     const std::string ppl = std::to_string(shape.pixels_per_lane);
     if (nvec > 1) k += "    const gd_u32 x0 = blockIdx.x * " + std::to_string(shape.wg * shape.pixels_per_lane) + "u + threadIdx.x * 4u;\n";
     else k += "    const gd_u32 x0 = (blockIdx.x * " + wg + "u + threadIdx.x) * " + ppl + "u;\n";
-    k += "    const gd_u32 ty = P.row0 + blockIdx.y;\n";
     k += "    if (x0 >= P.w) return;\n";
+    // A lane walks rows_per_lane rows of its columns, one after the other: whatever a pipeline computes from the column
+    // alone (v_uv.x, uv.x, p.x, a spectrum, a bloom on it ...) does not change from row to row and leaves the loop.
+    const std::string rpl = std::to_string(shape.rows_per_lane);
+    if (shape.rows_per_lane > 1) {
+        k += "#pragma nounroll\n    for (gd_u32 ry = 0; ry < " + rpl + "u; ++ry) {\n";
+        k += "    const gd_u32 ty = P.row0 + blockIdx.y * " + rpl + "u + ry;\n";
+        k += "    if (ty >= P.row0 + P.rows) break;\n";
+    } else {
+        k += "    {\n    const gd_u32 ty = P.row0 + blockIdx.y;\n";
+    }
     k += "    const gd_u32 fidx = blockIdx.z;\n";
     k += "    const float* __restrict__ U = P.utab + (unsigned long long)(P.frame0 + fidx) * P.ustride;\n";
     // slot0 < ring and fidx < ring (checked by the host), so one conditional subtract wraps the ring
@@ -314,6 +323,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
         k += "    dst[x] = gd_pack_rgba8(fr, fg, fb, fa);\n";
         k += "    }\n    }\n";
     }
+    k += "    }\n";   // rows of this lane
     k += "}\n";
     return k;
 }

@@ -7,6 +7,7 @@ namespace game {
 
 struct KernelShape {
     uint32_t pixels_per_lane = 1;   // consecutive pixels in x handled by one lane
+    uint32_t rows_per_lane = 1;     // rows a lane walks (one workgroup row of the grid covers this many image rows)
     uint32_t time_slot = 0;         // index in the frame row of fract(u_time/120)*120
     uint32_t aspect_slot = 0;       // index in the frame row of u_resolution.x / u_resolution.y
     bool wgsl = false;              // builtins as worded by the reference's WebGPU emitter (wgsl.rs) where they differ

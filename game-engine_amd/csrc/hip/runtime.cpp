@@ -224,6 +224,21 @@ KernelShape shape_for(const Ir& ir, uint32_t width, uint32_t flags = 0)
         int v = atoi(e);
         if (v == 1 || ((v == 4 || v == 8 || v == 16) && width % 4u == 0u)) s.pixels_per_lane = (uint32_t)v;
     }
+    // Rows per lane. A lane that walks several rows of its columns computes what depends on the column alone once
+    // (the compiler moves it out of the row loop): the x half of the prologue for every cinematic, whole stages for
+    // pipelines that start from uv.x (spectrum and what follows it up to the first stage that reads y). Measured:
+    // c3 +31 % at 8 rows, c2 +8 % at 8, c1 +9 % at 4 (its 1024-row frames run out of workgroups beyond that).
+    // Memory cinematics keep one row per lane: the row loop would serialise their previous-frame loads (c4 -9 % at 2).
+    if (!ir.uses_memory) {
+        bool column_first = false;
+        for (const IrLayer& L : ir.layers)
+            if (L.is_pipeline && L.stage_count && ir.stages[L.stage_begin].builtin == B_SPECTRUM) column_first = true;
+        s.rows_per_lane = (heavy || column_first) ? 8u : 4u;
+    }
+    if (const char* e = getenv("GAME_HIP_RPL")) {   // tuning hook
+        int v = atoi(e);
+        if (v >= 1 && v <= 64) s.rows_per_lane = (uint32_t)v;
+    }
     if (const char* e = getenv("GAME_HIP_WG")) {    // tuning hook
         int v = atoi(e);
         if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) s.wg = (uint32_t)v;
@@ -315,7 +330,7 @@ int launch_frames_into(game_hip_ctx* c, uint32_t* out, uint32_t ring, const floa
     P.slut = c->slut;
     void* args[] = {&P};
     uint32_t gx = (c->w + c->shape.wg * c->shape.pixels_per_lane - 1u) / (c->shape.wg * c->shape.pixels_per_lane);
-    uint32_t gy = rows;   // one row per workgroup row; rows <= height <= 65535 is checked at creation
+    uint32_t gy = (rows + c->shape.rows_per_lane - 1u) / c->shape.rows_per_lane;   // rows <= height <= 65535 is checked at creation
     HIP_TRY(hipModuleLaunchKernel(c->fn, gx, gy, count, c->shape.wg, 1, 1, c->lds_bytes, c->stream, args, nullptr));
     return GAME_OK;
 }

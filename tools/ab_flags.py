@@ -5,23 +5,24 @@ import os, sys, statistics
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import conftest as T
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-import bench
 g = T.load_product()
 key = sys.argv[1]
 variants = sys.argv[2:] or [""]
-cfg = bench.CONFIGS[key]
+cfg = g.workloads.CONFIGS[key]
 cin = g.compile(cfg["src"]).cinematics[0]
-w, h, batch = cfg["w"], cfg["h"], 10
+w, h, batch = cfg["w"], cfg["h"], 25
 rows = cin.uniform_rows([k / 60 for k in range(batch)], w, h, audio={"bass": 0.8, "mid": 0.6, "treble": 0.4})
 rs = []
 ref = None
 for v in variants:
-    # a variant is hiprtc flags, optionally prefixed by "PPL=n;" (pixels per lane)
-    ppl, _, fl = v.partition(";") if v.startswith("PPL=") else ("", "", v)
+    # a variant is hiprtc flags, optionally prefixed by shape settings: "PPL=n,RPL=m;flags" (pixels / rows per lane)
+    head, _, fl = v.partition(";") if v.startswith(("PPL=", "RPL=")) else ("", "", v)
     os.environ["GAME_HIP_FLAGS"] = fl
-    os.environ.pop("GAME_HIP_PPL", None)
-    if ppl: os.environ["GAME_HIP_PPL"] = ppl[4:]
+    for name in ("PPL", "RPL"):
+        os.environ.pop("GAME_HIP_" + name, None)
+    for item in filter(None, head.split(",")):
+        name, _, val = item.partition("=")
+        os.environ["GAME_HIP_" + name] = val
     r = cin.renderer(w, h); r.set_ring(max(2, batch))
     band = r.render_band(rows[:1], h // 2, 8)[0]
     if ref is None: ref = band
