@@ -394,7 +394,7 @@ def main():
         out = time_frames(args, game, torch, rank, world, local, args.config, args.steps, args.warmup, True)
     if rank == 0 and world == 1 and args.config == "c2" and not args.no_others and not args.frames and not args.batch:
         others = {}
-        for key, steps in (("c1", 10), ("c2b", 5), ("c3", 10), ("c4", 3)):
+        for key, steps in (("c1", 20), ("c2b", 5), ("c3", 20), ("c4", 3)):
             others[key] = brief(time_frames(args, game, torch, rank, world, local, key, steps, 1, False))
         others["c5"] = brief(time_particles(args, game, torch, rank, world, local, 1048576, 3, 1, False))
         out["other_configs"] = others

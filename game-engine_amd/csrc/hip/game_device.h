@@ -108,41 +108,41 @@ GD float gd_length2(float x, float y) { return gd_sqrt(__builtin_fmaf(x, x, y * 
 // ── sin / cos / atan ────────────────────────────────────────────────────────────────────
 // GLSL does not fix the precision of these; the render path uses a fixed algorithm made of
 // correctly rounded operations only, so every IEEE machine gets the same bits:
-// k = rint(x * 2/pi), three-constant Cody-Waite reduction with fma for |x| <= 32768, double
-// precision two-constant reduction up to 2^31, argument treated as 0 beyond; Cephes
-// single-precision minimax polynomials on [-pi/4, pi/4]; quadrant from k mod 4.
+// k = rint(x / pi), r = x - k pi by a three-constant Cody-Waite reduction with fma for |x| <= 32768 (a two-constant
+// double precision reduction up to 2^31, argument treated as 0 beyond), so |r| <= pi / 2 and
+// sin(x) = (-1)^k S(r), cos(x) = (-1)^k C(r) with ONE odd and ONE even minimax polynomial on [-pi/2, pi/2]
+// (S: r + r^3 (S1 + S2 z + S3 z^2 + S4 z^3), 1.8 ulp; C: 1 - z/2 + z^2 (Q0 + ... + Q3 z^3), 7.4e-8 absolute; z = r^2).
+// One reduction serves both functions and no quadrant selects are needed: a sine alone costs 14 instructions.
 GD void gd_sincos(float x, float& s_out, float& c_out)
 {
     float ax = gd_abs(x);
     float r;
-    int q;
+    gd_u32 sign;
     if (!(ax < __builtin_inff())) { s_out = c_out = x - x; return; }
     if (ax <= 32768.0f) {
-        float k = __builtin_rintf(x * 0.636619772f);
-        r = __builtin_fmaf(k, -1.5703125f, x);
-        r = __builtin_fmaf(k, -4.837512969970703125e-4f, r);
-        r = __builtin_fmaf(k, -7.54978995489188216e-8f, r);
-        q = (int)k & 3;
+        float k = __builtin_rintf(x * 0.318309886f);
+        r = __builtin_fmaf(k, -3.140625f, x);
+        r = __builtin_fmaf(k, -9.67502593994140625e-4f, r);
+        r = __builtin_fmaf(k, -1.509957990978376432e-7f, r);
+        sign = (gd_u32)(int)k << 31;
     } else if (ax >= 2147483648.0f) {
         r = 0.0f;
-        q = 0;
+        sign = 0u;
     } else {
         double xd = (double)x;
-        double kd = __builtin_rint(xd * 0.63661977236758134308);
-        double rd = __builtin_fma(-kd, 1.57079632673412561417e+00, xd);
-        rd = __builtin_fma(-kd, 6.07710050650619224932e-11, rd);
+        double kd = __builtin_rint(xd * 0.31830988618379067154);
+        double rd = __builtin_fma(-kd, 3.14159265346825122833, xd);
+        rd = __builtin_fma(-kd, 1.21542010130123844986e-10, rd);
         r = (float)rd;
-        q = (int)(kd - 4.0 * __builtin_floor(kd * 0.25));
+        sign = (gd_u32)(int)kd << 31;
     }
     float z = r * r;
-    float ps = __builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    float ps = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0x1.5c33e8p-19f, z, -0x1.9f5196p-13f), z, 0x1.110e1ap-7f), z, -0x1.555546p-3f);
     float s = __builtin_fmaf(ps * z, r, r);
-    float pc = __builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    float pc = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-0x1.184e1ap-22f, z, 0x1.9f7afap-16f), z, -0x1.6c1410p-10f), z, 0x1.55554ep-5f);
     float c = __builtin_fmaf(pc * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
-    float ss = (q & 1) ? c : s;
-    float cc = (q & 1) ? s : c;
-    s_out = (q & 2) ? -ss : ss;
-    c_out = ((q + 1) & 2) ? -cc : cc;
+    s_out = gd_from_bits(gd_bits(s) ^ sign);
+    c_out = gd_from_bits(gd_bits(c) ^ sign);
 }
 GD float gd_sin(float x) { float s, c; gd_sincos(x, s, c); return s; }
 GD float gd_cos(float x) { float s, c; gd_sincos(x, s, c); return c; }

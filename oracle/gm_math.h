@@ -64,49 +64,45 @@ static inline float gm_smoothstep(float e0, float e1, float x)
 static inline float gm_length2(float x, float y) { return sqrtf(fmaf(x, x, y * y)); }
 
 /* ── sin / cos ────────────────────────────────────────────────────────────────────────────
- * k = rint(x * 2/pi); r = x - k*pi/2 by three-constant Cody-Waite with fma for |x| <= 32768,
- * by two-constant double-precision reduction up to 2^31; beyond that (float spacing >= 256
- * radians) the argument counts as 0. Degree-7/8 minimax polynomials on [-pi/4, pi/4] (Cephes
- * single-precision coefficients); quadrant from k mod 4. */
-#define GM_TWO_OVER_PI 0.636619772f
-#define GM_PIO2_A 1.5703125f
-#define GM_PIO2_B 4.837512969970703125e-4f
-#define GM_PIO2_C 7.54978995489188216e-8f
+ * k = rint(x / pi); r = x - k*pi by three-constant Cody-Waite with fma for |x| <= 32768, by
+ * two-constant double-precision reduction up to 2^31; beyond that (float spacing >= 256
+ * radians) the argument counts as 0. sin(x) = (-1)^k S(r), cos(x) = (-1)^k C(r) with one odd and one even
+ * minimax polynomial on [-pi/2, pi/2] (fitted for this file: S within 1.8 ulp, C within 7.4e-8). */
+#define GM_ONE_OVER_PI 0.318309886f
+#define GM_PI_A 3.140625f
+#define GM_PI_B 9.67502593994140625e-4f
+#define GM_PI_C 1.509957990978376432e-7f
 
 static inline void gm_sincos(float x, float* s_out, float* c_out)
 {
     float ax = gm_abs(x);
     float r;
-    int q;
+    uint32_t sign;
     if (!(ax < INFINITY)) { *s_out = *c_out = x - x; return; }   /* inf, NaN -> NaN */
     if (ax <= 32768.0f) {
-        float k = rintf(x * GM_TWO_OVER_PI);
-        r = fmaf(k, -GM_PIO2_A, x);
-        r = fmaf(k, -GM_PIO2_B, r);
-        r = fmaf(k, -GM_PIO2_C, r);
-        q = (int)k & 3;
+        float k = rintf(x * GM_ONE_OVER_PI);
+        r = fmaf(k, -GM_PI_A, x);
+        r = fmaf(k, -GM_PI_B, r);
+        r = fmaf(k, -GM_PI_C, r);
+        sign = (uint32_t)(int)k << 31;
     } else if (ax >= 2147483648.0f) {
         r = 0.0f;
-        q = 0;
+        sign = 0u;
     } else {
         double xd = (double)x;
-        double kd = rint(xd * 0.63661977236758134308);
-        double rd = fma(-kd, 1.57079632673412561417e+00, xd);
-        rd = fma(-kd, 6.07710050650619224932e-11, rd);
+        double kd = rint(xd * 0.31830988618379067154);
+        double rd = fma(-kd, 3.14159265346825122833, xd);
+        rd = fma(-kd, 1.21542010130123844986e-10, rd);
         r = (float)rd;
-        q = (int)(kd - 4.0 * floor(kd * 0.25));
+        sign = (uint32_t)(int)kd << 31;
     }
     float z = r * r;
-    float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    float ps = fmaf(fmaf(fmaf(0x1.5c33e8p-19f, z, -0x1.9f5196p-13f), z, 0x1.110e1ap-7f), z, -0x1.555546p-3f);
     float s = fmaf(ps * z, r, r);
-    float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    float pc = fmaf(fmaf(fmaf(-0x1.184e1ap-22f, z, 0x1.9f7afap-16f), z, -0x1.6c1410p-10f), z, 0x1.55554ep-5f);
     float c = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
-    switch (q) {
-    case 0: *s_out = s; *c_out = c; break;
-    case 1: *s_out = c; *c_out = -s; break;
-    case 2: *s_out = -s; *c_out = -c; break;
-    default: *s_out = -c; *c_out = s; break;
-    }
+    *s_out = gm_from_bits(gm_bits(s) ^ sign);
+    *c_out = gm_from_bits(gm_bits(c) ^ sign);
 }
 static inline float gm_sin(float x) { float s, c; gm_sincos(x, &s, &c); return s; }
 static inline float gm_cos(float x) { float s, c; gm_sincos(x, &s, &c); return c; }
