@@ -228,7 +228,9 @@ KernelShape shape_for(const Ir& ir, uint32_t width, uint32_t flags = 0)
     // (the compiler moves it out of the row loop): the x half of the prologue for every cinematic, whole stages for
     // pipelines that start from uv.x (spectrum and what follows it up to the first stage that reads y). Measured:
     // c3 +31 % at 8 rows, c2 +8 % at 8, c1 +9 % at 4 (its 1024-row frames run out of workgroups beyond that).
-    // Memory cinematics keep one row per lane: the row loop would serialise their previous-frame loads (c4 -9 % at 2).
+    // Memory cinematics keep one row per lane: c4 loses 9 % at two rows with the previous-frame load inside the row loop
+    // and still 1.5 % (6 % at four rows) with all of a lane's loads requested up front - it runs near its memory
+    // floor and prefers many short waves.
     if (!ir.uses_memory) {
         bool column_first = false;
         for (const IrLayer& L : ir.layers)
