@@ -22,7 +22,11 @@ SIGNALS = ["time", "audio.bass", "audio.mid", "audio.treble", "audio.energy", "a
 
 
 EXPRESSIONS = ["time * 0.5 + 0.1", "sin(time * 2.0) * 0.2 + 0.3", "audio.bass * 0.5", "0.2 + mouse.x * 0.3", "abs(cos(time)) * knob",
-               "mix(0.1, 0.6, audio.beat)", "-(mouse.y - 0.5)", "2.0 ^ audio.mid", "min(time, 1.5)", "p.x * 2.0", "nothing * 3.0"]
+               "mix(0.1, 0.6, audio.beat)", "-(mouse.y - 0.5)", "2.0 ^ audio.mid", "min(time, 1.5)", "p.x * 2.0", "nothing * 3.0",
+               # vector-valued subexpressions and the scalar functions added with them
+               "length(p) * 0.5", "dot(uv, [0.3, 0.4]) + 0.2", "distance(p, [0.2 * knob, -0.1])", "dot(normalize(p), [0.6, 0.8])",
+               "length(p * 2.0 - uv) * 0.3", "mod(p.x * 3.0 + time, 0.7)", "atan2(p.y, p.x) * 0.2", "round(uv.y * 4.0) * 0.1",
+               "length(abs(p) - [0.3, 0.2])", "p * 2.0"]
 
 
 def make_cinematic(game, rng, expressions=False):
@@ -66,10 +70,13 @@ def make_cinematic(game, rng, expressions=False):
             mem = f" memory: {rng.choice([0.5, 0.9, 0.97, 0.0, 1.0])}"
             uses_memory = True
         layers.append(f"  layer l{li}{mem} {{ fn: {' | '.join(stages)} }}")
-    if expressions:   # a lens post chain too
+    tail = ""
+    if expressions:   # a lens post chain too, and sometimes a projection block
         post = [call(rng.choice(table[("Color", "Color")])) for _ in range(rng.randint(1, 3))]
         layers.append(f"  lens {{ post: {' | '.join(post)} }}")
-    return 'cinematic "fuzz" {\n' + "\n".join(layers) + "\n}", uses_memory
+        if rng.random() < 0.4:
+            tail = "\nproject " + rng.choice(["dome (fisheye: 150)", "dome", "led (count: 12)", "cube", "flat"]) + " { source: fuzz }"
+    return 'cinematic "fuzz" {\n' + "\n".join(layers) + "\n}" + tail, uses_memory
 
 
 def frames_and_rows(game, src, rng, w, h):
@@ -127,15 +134,16 @@ def test_gpu_matches_oracle_on_generated_cinematics(game, oracle, seed):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(100, 130))
 def test_gpu_matches_oracle_with_expression_arguments_and_lens_post(game, oracle, seed):
-    """The opt-in extensions together: expression-valued arguments evaluated per frame and the lens post chain."""
+    """The opt-in extensions together: expression-valued arguments evaluated per frame (scalar and vector-valued
+    subexpressions), the lens post chain and, for some seeds, a projection block."""
     rng = random.Random(seed)
     src, _ = make_cinematic(game, rng, expressions=True)
     w, h = rng.choice([(96, 54), (100, 37), (64, 64)])
     cin, rows = frames_and_rows(game, src, rng, w, h)
     derived = cin.eval_derived(rows)
     sem = rng.choice(["glsl", "wgsl"])
-    r = cin.renderer(w, h, semantics=sem, animate=True, lens_post=True)
+    r = cin.renderer(w, h, semantics=sem, animate=True, lens_post=True, project=True)
     got = r.render(rows)
     r.close()
-    want = oracle.render_sequence(cin.blob, w, h, rows, cin.uses_memory, semantics=sem, derived=derived, lens_post=True)
+    want = oracle.render_sequence(cin.blob, w, h, rows, cin.uses_memory, semantics=sem, derived=derived, lens_post=True, project=True)
     assert np.array_equal(got, want), f"seed {seed} ({sem})\n{src}"

@@ -24,10 +24,10 @@ for seed in range(first, last):
         continue
     derived = cin.eval_derived(rows) if ext else None
     for sem in ("glsl", "wgsl"):
-        r = cin.renderer(w, h, semantics=sem, animate=ext, lens_post=ext)
+        r = cin.renderer(w, h, semantics=sem, animate=ext, lens_post=ext, project=ext)
         got = r.render(rows)
         r.close()
-        want = oracle.render_sequence(cin.blob, w, h, rows, cin.uses_memory, semantics=sem, derived=derived, lens_post=ext, animate=ext)
+        want = oracle.render_sequence(cin.blob, w, h, rows, cin.uses_memory, semantics=sem, derived=derived, lens_post=ext, animate=ext, project=ext)
         if not np.array_equal(got, want):
             bad += 1
             print("MISMATCH seed", seed, sem, int((got != want).sum()), "values\n" + src, flush=True)
