@@ -118,6 +118,7 @@ def _load():
         "game_hip_particles_read": (c.c_int, [vp, vp, vp]),
         "game_hip_particles_positions": (c.c_int, [vp, c.POINTER(vp), c.POINTER(vp)]),
         "game_hip_particles_time": (c.c_int, [vp, c.POINTER(f32)]),
+        "game_hip_shutdown": (c.c_int, []),
         "game_hip_eval": (c.c_int, [c.c_int, u32, vp, vp, vp]),
         "game_hip_check_exhaustive": (c.c_int, [c.c_int, c.POINTER(u64), c.POINTER(u32)]),
     }
@@ -343,6 +344,11 @@ def device_count():
     n = ctypes.c_int()
     _check(lib.game_hip_device_count(ctypes.byref(n)))
     return n.value
+
+
+def shutdown():
+    """Frees the per-device lattice tables (every Renderer must be closed first)."""
+    _check(lib.game_hip_shutdown())
 
 
 def pinned_array(shape):

@@ -18,7 +18,7 @@
 using namespace game;
 
 // the ahead-of-time HIP part is not linked into this build
-namespace game { int lut_for_current_device(int, const float**) { return GAME_E_NO_DEVICE; } }
+namespace game { int lut_for_current_device(int, const float**) { return GAME_E_NO_DEVICE; } int release_device_tables() { return GAME_OK; } }
 
 int main(int argc, char** argv)
 {

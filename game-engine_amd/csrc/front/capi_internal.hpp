@@ -2,6 +2,7 @@
 #pragma once
 #include "front.hpp"
 #include "../../../include/game_hip.h"
+#include "../../../include/game_hip_diag.h"
 #include <string>
 #include <vector>
 
@@ -23,5 +24,7 @@ int set_error(int code, const std::string& msg);
 // points, 2 = simplex corners. Built on first use and kept for the life of the process. Defined with the ahead-of-time
 // kernels; returns a GAME_E_* code.
 int lut_for_current_device(int kind, const float** table);
+// Frees every table built so far (game_hip_shutdown).
+int release_device_tables();
 int error_code_of(const CompileError& e);
 }  // namespace game

@@ -104,6 +104,11 @@ __global__ void exhaustive_kernel(int which, unsigned long long* mismatches, uin
             float want = which == 3 ? __builtin_sqrtf(x) : 1.0f / x;
             bool same = (hw != hw && want != want) || gd_bits(hw) == gd_bits(want);
             if (!same) { ++bad; atomicMin(first_bad, (gd_u32)v); }
+        } else if (which == 6) {
+            float t = __builtin_rintf(x);
+            gd_u32 want = (x != x || !(t > 0.0f)) ? 0u : (t >= 255.0f ? 255u : (gd_u32)t);
+            gd_u32 lo = __builtin_amdgcn_cvt_pk_u8_f32(x, 0u, 0u), mid = __builtin_amdgcn_cvt_pk_u8_f32(x, 2u, 0xffffffffu);
+            if (lo != want || mid != (0xff00ffffu | (want << 16))) { ++bad; atomicMin(first_bad, (gd_u32)v); }
         } else if (which == 5) {
             if (!(x >= 0x1p-100f && x < __builtin_inff())) continue;
             float root, inv;
@@ -143,10 +148,28 @@ struct DevBuf {
 
 namespace game {
 
+static std::mutex g_tables_mu;
+static std::map<int, float*> g_tables;   // key = device * 4 + kind
+
+int release_device_tables()
+{
+    std::lock_guard<std::mutex> lock(g_tables_mu);
+    int prev = 0;
+    hipError_t e = hipGetDevice(&prev);
+    for (auto& kv : g_tables) {
+        if (e == hipSuccess) e = hipSetDevice(kv.first / 4);
+        if (e == hipSuccess) e = hipFree(kv.second);
+    }
+    g_tables.clear();
+    if (e == hipSuccess) e = hipSetDevice(prev);
+    if (e != hipSuccess) return hip_err("game_hip_shutdown", e);
+    return GAME_OK;
+}
+
 int lut_for_current_device(int kind, const float** table)
 {
-    static std::mutex mu;
-    static std::map<int, float*> tables;   // key = device * 4 + kind
+    std::mutex& mu = g_tables_mu;
+    std::map<int, float*>& tables = g_tables;
     if (kind < 0 || kind > 2) return set_error(GAME_E_ARGUMENT, "lut_for_current_device: unknown table");
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
@@ -176,6 +199,8 @@ int lut_for_current_device(int kind, const float** table)
 
 extern "C" {
 
+int game_hip_shutdown(void) { return release_device_tables(); }
+
 int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out)
 {
     if (op < 0 || op >= EV_COUNT || !a || !out || n == 0) return set_error(GAME_E_ARGUMENT, "game_hip_eval: bad argument");
@@ -198,7 +223,7 @@ int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out
 
 int game_hip_check_exhaustive(int which, uint64_t* mismatches, uint32_t* first_bad)
 {
-    if (which < 0 || which > 5 || !mismatches || !first_bad) return set_error(GAME_E_ARGUMENT, "game_hip_check_exhaustive: bad argument");
+    if (which < 0 || which > 6 || !mismatches || !first_bad) return set_error(GAME_E_ARGUMENT, "game_hip_check_exhaustive: bad argument");
     DevBuf dm, df;
     HIP_TRY(dm.alloc(8));
     HIP_TRY(df.alloc(4));

@@ -314,22 +314,10 @@ int game_hip_particles_time(game_hip_ctx* ctx, float* sim_time);
 /* Resume: the simulation time a restored particle state continues from (particles_init resets it to 0). */
 int game_hip_particles_set_time(game_hip_ctx* ctx, float sim_time);
 
-/* ── diagnostics (no counterpart in the reference) ─────────────────────────────────────────
- * Element-wise evaluation of the device math / noise functions on host arrays, so that tests can
- * compare them bit-for-bit with a CPU restatement. op: 0 fract, 1 sin, 2 cos, 3 atan2(a,b),
- * 4 hash2(a,b), 5 noise2(a,b), 6 simplex2d(a,b), 7 voronoi2d(a,b,5), 8 exp2, 9 log2, 10 pow(a,b),
- * 11 max(a,b), 12 min(a,b), 13 fbm2(a,b,6,.5,2), 14 sqrt, 15 a/b, 16 smoothstep(.005,-.005,a),
- * 17 mod(a,b), 18 texel fetch: float of the byte (uint)a, 19 / 20 noise2 / fbm2 through the lattice-hash table,
- * 21 voronoi2d(a,b,5) through the feature-point table, 22 simplex2d(a,b) through the corner table, 23 the byte the
- * framebuffer write stores for the colour value a.
- * b may be NULL for one-argument ops. */
-int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out);
-/* Exhaustive check, over all 2^32 float bit patterns, that the hardware instruction equals its
- * defining formula: which 0 = v_fract_f32 vs min(x - floor(x), 1 - 2^-24); 1 / 2 = v_max_f32 /
- * v_min_f32 vs "NaN yields the other operand, -0 < +0" against probe constants; 3 / 4 = the short
- * v_rsq_f32 / v_rcp_f32 + fma sequences of the render path vs correctly rounded sqrt(x) and 1/x; 5 = the joint root / reciprocal-of-root
- * sequence of the gravity kernel vs sqrtf(x) and 1/sqrtf(x) for 2^-100 <= x < inf. */
-int game_hip_check_exhaustive(int which, uint64_t* mismatches, uint32_t* first_bad);
+/* Releases what the library keeps per device for the life of the process (the lattice tables of game_device.h). Every
+ * context must have been destroyed first; later contexts rebuild what they need. The browser counterpart is the page
+ * going away. */
+int game_hip_shutdown(void);
 
 #ifdef __cplusplus
 }

@@ -80,3 +80,17 @@ def test_position_exchange_over_rccl_single_rank(game, oracle):
         assert full.tolist() == list(range(10))
     finally:
         dist.destroy_process_group()
+
+
+def test_shutdown_releases_tables_and_later_contexts_rebuild_them(game, oracle):
+    from conftest import C2B_NOISE
+    cin = game.compile(C2B_NOISE).cinematics[0]        # uses the lattice, feature-point and simplex tables
+    w, h = 96, 54
+    rows = cin.uniform_rows([0.25], w, h)
+    want = oracle.render(cin.blob, w, h, rows[0])
+    for _ in range(2):
+        r = cin.renderer(w, h)
+        assert np.array_equal(r.render(rows)[0], want)
+        r.close()
+        game.shutdown()
+    game.shutdown()                                    # nothing left: still fine

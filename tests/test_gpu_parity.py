@@ -43,7 +43,7 @@ def test_device_present(game):
 
 
 # ── hardware instructions vs their defining formulas, all 2^32 inputs ───────────────────
-@pytest.mark.parametrize("which", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("which", [0, 1, 2, 3, 4, 5, 6])
 def test_exhaustive_instruction_semantics(game, which):
     mismatches, first = game.check_exhaustive(which)
     assert mismatches == 0, hex(first)
