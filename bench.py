@@ -239,7 +239,8 @@ def time_frames(args, game, torch, rank, world, local, key, steps, warmup, extra
         per_launch_frames = 1 if banded else batch
         px_launch = (nrows if banded else h) * w * per_launch_frames
         sec = kernel_ms / launches / 1e3
-        pmc = measured_counters(key, per_launch_frames, r.kernel_hash) if world == 1 else None
+        # the counters describe one launch of this kernel build; a band launch (N > 1, memory cinematics) is another shape
+        pmc = measured_counters(key, per_launch_frames, r.kernel_hash) if (world == 1 or not banded) else None
         if cfg["bound"] == "valu":
             roof = valu_roofline(pmc, sec, px_launch * cfg["flops_px"])
             roof["flops_per_pixel"] = cfg["flops_px"]
