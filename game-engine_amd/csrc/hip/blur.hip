@@ -73,7 +73,15 @@ __global__ __launch_bounds__(256) void blur_kernel(const uint32_t* __restrict__ 
     __shared__ __attribute__((aligned(16))) uint32_t in[IH][IWP];   // column 0 = frame column x0 - 4
     __shared__ __attribute__((aligned(16))) uint32_t mid[IH][TX];
     const uint32_t tid = threadIdx.x;
-    const int x0 = (int)(blockIdx.x * TX), y0 = (int)(row0 + blockIdx.y * TY);
+    // Workgroups are handed to the eight XCDs round robin, and each XCD has its own L2. Neighbouring tiles share their
+    // halo pixels (and the 128-byte lines their edges sit in), so the launch is one-dimensional and workgroup L takes
+    // tile (L mod 8) * chunk + L / 8: every XCD works through one contiguous eighth of the tile grid, in order, and
+    // finds its neighbours' lines in its own L2 (measured: HBM reads 2.0x the frame without this, see the profile).
+    const uint32_t tiles_x = (w + TX - 1u) / TX, tiles = tiles_x * ((rows + TY - 1u) / TY);
+    const uint32_t chunk = (tiles + 7u) / 8u;
+    const uint32_t tile = (blockIdx.x % 8u) * chunk + blockIdx.x / 8u;
+    if (tile >= tiles) return;                            // the whole workgroup leaves, before any barrier
+    const int x0 = (int)((tile % tiles_x) * TX), y0 = (int)(row0 + (tile / tiles_x) * TY);
     // all loads of the lane are issued before the first one is waited for (a fixed, unrolled count)
     constexpr uint32_t NLOAD = (CH * IH + 255u) / 256u;
     u32x4 held[NLOAD];
@@ -146,7 +154,8 @@ int launch_blur(const uint32_t* raw, uint32_t* out, uint32_t w, uint32_t h, uint
 {
     if (!raw || !out || radius < 1 || radius > 4 || rows == 0 || (uint64_t)row0 + rows > h)
         return set_error(GAME_E_ARGUMENT, "blur: radius must be 1..4 and the band inside the frame");
-    const dim3 grid((w + TX - 1) / TX, (rows + TY - 1) / TY), block(256);
+    const uint32_t tiles = ((w + TX - 1) / TX) * ((rows + TY - 1) / TY);
+    const dim3 grid(((tiles + 7u) / 8u) * 8u), block(256);
     // 16-byte tile moves need every row (and the two frame pointers) on a 16-byte boundary
     const bool vec = w % 4u == 0u && ((uintptr_t)raw & 15u) == 0u && ((uintptr_t)out & 15u) == 0u;
 #define GAME_BLUR_CASE(R)                                                                                             \

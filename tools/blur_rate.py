@@ -12,10 +12,12 @@ import conftest as T  # noqa: E402
 game = T.load_product()
 W = game.workloads
 cin = game.compile(W.C4_TRAILS).cinematics[0]
-w, h, n = 7680, 4320, 100
+w, h = 7680, 4320
+radii = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 3, 4]     # e.g. "0,4"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 rows = W.frame_rows(cin, "c4", range(n), w, h)
 base = None
-for radius in (0, 1, 2, 3, 4):
+for radius in radii:
     r = cin.renderer(w, h)
     r.set_blur(radius)
     r.render(rows[:10], readback=False)
@@ -24,8 +26,8 @@ for radius in (0, 1, 2, 3, 4):
     ms, launches = r.last_kernel_ms()
     r.close()
     per = ms / n
-    if radius == 0:
-        base = per
+    if radius == 0 or base is None:
+        base = per if radius == 0 else 0.0
         print(f"no filter: {per * 1e3:.1f} us/frame", flush=True)
     else:
         blur = per - base
