@@ -295,10 +295,10 @@ def time_frames(args, game, torch, rank, world, local, key, steps, warmup, extra
     return out
 
 
-def time_particles(args, game, torch, rank, world, local, n, steps, warmup, extras):
+def time_particles(args, game, torch, rank, world, local, n, steps, warmup, extras, fast=False):
     cin = game.compile(game.workloads.C5_GRAVITY).cinematics[0]
     first, count = game.distributed.particle_range(n, rank, world)
-    r = cin.renderer(16, 16, device=local)
+    r = cin.renderer(16, 16, device=local, gravity_fast=fast)
     r.particles_seed(n)
     gather = game.distributed.PositionExchange(r, n, first, count, torch) if world > 1 else None
 
@@ -328,13 +328,14 @@ def time_particles(args, game, torch, rank, world, local, n, steps, warmup, extr
     out = {"metric": "Mpair/s (gravity all-pairs)", "value": round(pairs / dt / 1e6, 1), "unit": "Mpair/s", "n_gpus": world,
            "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"examples/010-gravity-particles.game, {n} particles, all-pairs, dt=1/60", "particles": n,
+           "config": {"workload": f"examples/010-gravity-particles.game, {n} particles, all-pairs, dt=1/60" +
+                                  (" (fast arithmetic: not a parity mode)" if fast else ""), "particles": n,
                       "parallelism": f"index{world}"},
            "timed_region_s": round(dt, 4)}
     if rank == 0 and args.events and launches:
         sec = kernel_ms / launches / 1e3
         flops = 20.0 * count * (n - 1) + 12.0 * count
-        pmc = measured_counters("c5", n, r.kernel_hash) if world == 1 else None
+        pmc = measured_counters("c5", n, r.kernel_hash) if world == 1 and not fast else None
         roof = valu_roofline(pmc, sec, flops)
         # for the particle kernel the flop convention (20 per pair) is below the arithmetic peak by construction, so
         # it stays the headline fraction; the issue-slot occupancy is reported beside it
@@ -357,6 +358,32 @@ def time_particles(args, game, torch, rank, world, local, n, steps, warmup, extr
                                "sample": f"one step of {m} particles ({dtc:.1f} s, {threads} threads)"}
     r.close()
     return out
+
+
+def time_filtered_feedback(game, local, radius, frames):
+    """The 8K feedback cinematic with the frame filter on: fused kernel into the raw frame + blur into the ring slot,
+    per frame. Frames stay in HBM; both kernels are inside the timed span."""
+    W = game.workloads
+    cfg = W.CONFIGS["c4"]
+    cin = game.compile(cfg["src"]).cinematics[0]
+    w, h = cfg["w"], cfg["h"]
+    r = cin.renderer(w, h, device=local)
+    r.set_blur(radius)
+    rows = W.frame_rows(cin, "c4", range(frames), w, h)
+    r.render(rows[:10], readback=False)
+    r.sync()
+    t0 = time.perf_counter()
+    r.render(rows, readback=False)
+    r.sync()
+    dt = time.perf_counter() - t0
+    ms, launches = r.last_kernel_ms()
+    r.close()
+    return {"value": round(frames * w * h / dt / 1e6, 1), "unit": "Mpixel/s", "steps": 1, "ms_per_step": round(dt * 1e3, 4),
+            "timed_region_s": round(dt, 4),
+            "workload": f"{cfg['workload']}, every frame blurred (binomial, radius {radius}) before it is stored and fed back",
+            "roofline": {"bound": "hbm", "achieved": round(frames * w * h * 16 / (ms / 1e3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(frames * w * h * 16 / (ms / 1e3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None, "bytes_per_pixel": 16,
+                         "kernel": "game_frame + blur_kernel", "avg_launch_ms": round(ms / launches, 4), "launches_timed": launches}}
 
 
 def brief(rec):
@@ -398,6 +425,8 @@ def main():
         for key, steps in (("c1", 20), ("c2b", 5), ("c3", 20), ("c4", 3)):
             others[key] = brief(time_frames(args, game, torch, rank, world, local, key, steps, 1, False))
         others["c5"] = brief(time_particles(args, game, torch, rank, world, local, 1048576, 3, 1, False))
+        others["c5_fast"] = brief(time_particles(args, game, torch, rank, world, local, 1048576, 3, 1, False, fast=True))
+        others["c4_blur4"] = time_filtered_feedback(game, local, 4, 100)
         out["other_configs"] = others
     if rank == 0:
         if REHEARSE:
