@@ -209,6 +209,11 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     if (nvec > 1) k += "    const gd_u32 x0 = blockIdx.x * " + std::to_string(shape.wg * shape.pixels_per_lane) + "u + threadIdx.x * 4u;\n";
     else k += "    const gd_u32 x0 = (blockIdx.x * " + wg + "u + threadIdx.x) * " + ppl + "u;\n";
     k += "    if (x0 >= P.w) return;\n";
+    // The uniform row is read through the constant address space: nothing writes it while the kernel runs, so its
+    // loads are scalar and invariant. Every slot the pipeline reads is loaded here, ahead of the row loop, so that
+    // whatever is computed from uniforms and the column alone leaves the loop with them.
+    k += "    const gd_uniform_row U = (gd_uniform_row)(P.utab + (unsigned long long)(P.frame0 + blockIdx.z) * P.ustride);\n";
+    const size_t uniform_loads_at = k.size();
     // A lane walks rows_per_lane rows of its columns, one after the other: whatever a pipeline computes from the column
     // alone (v_uv.x, uv.x, p.x, a spectrum, a bloom on it ...) does not change from row to row and leaves the loop.
     const std::string rpl = std::to_string(shape.rows_per_lane);
@@ -220,7 +225,6 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
         k += "    {\n    const gd_u32 ty = P.row0 + blockIdx.y;\n";
     }
     k += "    const gd_u32 fidx = blockIdx.z;\n";
-    k += "    const float* __restrict__ U = P.utab + (unsigned long long)(P.frame0 + fidx) * P.ustride;\n";
     // slot0 < ring and fidx < ring (checked by the host), so one conditional subtract wraps the ring
     k += "    const gd_u32 slot_raw = P.slot0 + fidx;\n";
     k += "    const gd_u32 slot = slot_raw >= P.ring ? slot_raw - P.ring : slot_raw;\n";
@@ -325,6 +329,21 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     }
     k += "    }\n";   // rows of this lane
     k += "}\n";
+    // U[n] in the body becomes the scalar u_n loaded once at the top
+    std::string loads;
+    std::vector<bool> seen;
+    for (size_t at = k.find("U[", uniform_loads_at); at != std::string::npos; at = k.find("U[", at)) {
+        size_t end = at + 2;
+        unsigned n = 0;
+        while (end < k.size() && k[end] >= '0' && k[end] <= '9') n = n * 10u + (unsigned)(k[end++] - '0');
+        if (end == at + 2 || end >= k.size() || k[end] != ']' || (at > 0 && (isalnum((unsigned char)k[at - 1]) || k[at - 1] == '_'))) { at = end; continue; }
+        const std::string name = "u_" + std::to_string(n);
+        k.replace(at, end + 1 - at, name);
+        if (seen.size() <= n) seen.resize(n + 1, false);
+        if (!seen[n]) { seen[n] = true; loads += "    const float " + name + " = U[" + std::to_string(n) + "];\n"; }
+        at += name.size();
+    }
+    k.insert(uniform_loads_at, loads);
     return k;
 }
 

@@ -16,6 +16,8 @@
 #define GD static __device__ __forceinline__
 
 typedef unsigned int gd_u32;
+// One frame's uniform row, as read-only memory of the whole launch (constant address space: scalar, invariant loads).
+typedef const __attribute__((address_space(4))) float* gd_uniform_row;
 typedef gd_u32 gd_u32x4 __attribute__((ext_vector_type(4)));
 typedef float gd_f32x2 __attribute__((ext_vector_type(2)));
 typedef float gd_f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));   // 16-byte load at 8-byte alignment
