@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 PEAK_FP32_TFLOPS = 157.3          # MI355X vector FP32 peak: 256 CU x 4 SIMD x 32 lanes x 2 (fma) x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 REHEARSE = os.environ.get("GAME_BENCH_REHEARSE") == "1"   # not a measurement mode: see dist_setup
+CONTROL_BACKEND = "nccl"    # what carries the barrier and the max over ranks at N > 1 (dist_setup may fall back to gloo)
 SIMDS, CLOCK_HZ = 1024, 2.4e9     # 256 CUs x 4 SIMDs; one wave64 VALU instruction per 2 cycles per SIMD at best
 
 
@@ -116,7 +117,20 @@ def dist_setup(n_gpus):
         if REHEARSE:
             dist.init_process_group(backend="gloo")
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+            try:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)          # the communicator works before anything is timed
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
+            except Exception as e:              # RCCL unusable on this node: the frame-sharded configs need only a
+                global CONTROL_BACKEND          # barrier and a max over ranks, which gloo provides as well
+                print(f"rank {rank}: RCCL start-up failed ({type(e).__name__}: {e}); control collectives over gloo", file=sys.stderr, flush=True)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group(backend="gloo")
+                CONTROL_BACKEND = "gloo"
     return torch, rank, world, local
 
 
@@ -132,7 +146,7 @@ def max_over_ranks(torch, world, value):
     if world == 1:
         return value
     import torch.distributed as dist
-    t = torch.tensor([value], dtype=torch.float64, device="cpu" if REHEARSE else "cuda")
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if (REHEARSE or CONTROL_BACKEND == "gloo") else "cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -429,6 +443,8 @@ def main():
         others["c4_blur4"] = time_filtered_feedback(game, local, 4, 100)
         out["other_configs"] = others
     if rank == 0:
+        if world > 1:
+            out["control_backend"] = "gloo" if REHEARSE else CONTROL_BACKEND
         if REHEARSE:
             out["data"] = "synthetic (REHEARSAL: all ranks on one GPU, not a measurement)"
         print(json.dumps(out), flush=True)
