@@ -60,6 +60,7 @@ def _load():
         "game_front_ast_json": (c.c_char_p, [c.c_char_p, sz, c.c_int]),
         "game_builtin_count": (sz, []),
         "game_builtin_describe": (c.c_char_p, [sz]),
+        "game_ir_from_blob": (c.c_int, [vp, sz, c.POINTER(vp)]),
         "game_ir_name": (c.c_char_p, [vp]),
         "game_ir_json": (c.c_char_p, [vp]),
         "game_ir_blob": (sz, [vp, c.POINTER(vp)]),
@@ -264,11 +265,14 @@ class Cinematic:
 class Program:
     """Result of compiling .game source (reference: game_compiler::compile, game-compiler/src/lib.rs:117)."""
 
-    def __init__(self, source, base_dir=None, lib_dirs=()):
+    def __init__(self, source, base_dir=None, lib_dirs=(), blob=None):
         if isinstance(source, str):
             source = source.encode("utf-8")
         h = ctypes.c_void_p()
-        if base_dir is None:
+        if blob is not None:    # a resolved IR handed over as data (game_ir_from_blob)
+            blob = bytes(blob)
+            _check(lib.game_ir_from_blob(blob, len(blob), ctypes.byref(h)))
+        elif base_dir is None:
             _check(lib.game_front_compile(source, len(source), ctypes.byref(h)))
         else:       # file imports resolved against base_dir, then lib_dirs (reference: resolver::resolve_imports)
             dirs = (ctypes.c_char_p * max(len(lib_dirs), 1))(*[os.fsencode(d) for d in lib_dirs])
@@ -288,6 +292,12 @@ class Program:
 def compile(source, base_dir=None, lib_dirs=()):
     """base_dir=None: file imports are left alone, as the reference's compile() does; otherwise they are resolved."""
     return Program(source, base_dir, lib_dirs)
+
+
+def load_blob(blob):
+    """A program of one cinematic from a resolved-IR blob (layout in include/game_hip.h), validated; raises GameError
+    for a blob that is damaged or names things that do not exist."""
+    return Program(None, blob=blob)
 
 
 def compile_file(path, lib_dirs=()):

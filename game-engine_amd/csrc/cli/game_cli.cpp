@@ -59,7 +59,8 @@ int usage()
             "                   [--cinematic I] [--out PREFIX|-] [--particles N --steps S]\n"
             "                   [--png] [--semantics glsl|wgsl] [--no-arcs] [--animate] [--lens-post] [--project] [--imports] [--lib DIR]... [--json] [--gpus N]\n"
             "       game compare A B [--threshold T]\n"
-            "       game ir FILE | game kernel FILE [--size WxH] | game builtins\n");
+            "       game ir FILE [--cinematic I --out X.gir] | game kernel FILE [--size WxH] | game builtins\n"
+            "       FILE is .game text or a resolved-IR blob (X.gir)\n");
     return 2;
 }
 
@@ -144,6 +145,13 @@ game_program* load_program(const std::string& path, const Args& a)
     if (!read_file(path, src)) { fprintf(stderr, "Error: read: %s\n", path.c_str()); return nullptr; }
     game_program* prog = nullptr;
     int rc;
+    if (src.size() >= 4 && memcmp(src.data(), "GIR1", 4) == 0) {   // a resolved-IR blob (game ir FILE --out X.gir, or a foreign host's)
+        if (game_ir_from_blob(src.data(), src.size(), &prog) != GAME_OK) {
+            fprintf(stderr, "Error: %s: %s\n", path.c_str(), game_last_error());
+            return nullptr;
+        }
+        return prog;
+    }
     if (a.imports) {   // imports are looked up next to the file, then in each --lib directory
         size_t slash = path.find_last_of('/');
         std::string base = slash == std::string::npos ? "." : path.substr(0, slash ? slash : 1);
@@ -469,11 +477,20 @@ int cmd_ir(const Args& a)
     if (a.files.size() != 1) return usage();
     game_program* prog = load_program(a.files[0], a);
     if (!prog) return 1;
-    printf("[");
-    for (size_t i = 0; i < game_program_cinematic_count(prog); ++i) printf("%s%s", i ? ",\n" : "", game_ir_json(game_program_ir(prog, i)));
-    printf("]\n");
+    int rc = 0;
+    if (!a.out.empty()) {   // the flat blob of one cinematic: what `game render X.gir` and game_ir_from_blob take
+        const void* data = nullptr;
+        const size_t n = a.cinematic < game_program_cinematic_count(prog) ? game_ir_blob(game_program_ir(prog, a.cinematic), &data) : 0;
+        FILE* f = n ? fopen(a.out.c_str(), "wb") : nullptr;
+        if (!f || fwrite(data, 1, n, f) != n) { fprintf(stderr, "Error: write: %s\n", a.out.c_str()); rc = 1; }
+        if (f) fclose(f);
+    } else {
+        printf("[");
+        for (size_t i = 0; i < game_program_cinematic_count(prog); ++i) printf("%s%s", i ? ",\n" : "", game_ir_json(game_program_ir(prog, i)));
+        printf("]\n");
+    }
     game_program_free(prog);
-    return 0;
+    return rc;
 }
 
 int cmd_kernel(const Args& a)

@@ -78,6 +78,23 @@ int game_front_compile_with_imports(const char* src, size_t len, const char* bas
     return finish_compile(p, e, source, out);
 }
 
+int game_ir_from_blob(const void* data, size_t len, game_program** out)
+{
+    if (!data || !out) return set_error(GAME_E_ARGUMENT, "game_ir_from_blob: null argument");
+    *out = nullptr;
+    auto* p = new game_program;
+    p->prog.irs.resize(1);
+    std::string why;
+    if (!ir_deserialize((const uint8_t*)data, len, p->prog.irs[0], why)) {
+        delete p;
+        g_last_rendered.clear();
+        return set_error(GAME_E_ARGUMENT, "game_ir_from_blob: " + why);
+    }
+    p->prog.blobs.push_back(ir_serialize(p->prog.irs[0]));
+    p->prog.jsons.push_back(ir_to_json(p->prog.irs[0]));
+    return finish_compile(p, CompileError{}, std::string(), out);
+}
+
 void game_program_free(game_program* p) { delete p; }
 size_t game_program_cinematic_count(const game_program* p) { return p ? p->irs.size() : 0; }
 const game_ir* game_program_ir(const game_program* p, size_t i) { return (p && i < p->irs.size()) ? &p->irs[i] : nullptr; }

@@ -321,6 +321,10 @@ bool eval_js_const(const Expr& e, double& out);
 Ir lower_cinematic(const Cinematic& c);                  // after validate; never fails
 std::vector<uint8_t> ir_serialize(const Ir& ir);         // flat little-endian blob (layout: include/game_hip.h)
 std::string ir_to_json(const Ir& ir);
+// The inverse of ir_serialize, for hosts that bring their own resolved IR: every index, count, string and program of the
+// blob is checked (a damaged or hostile blob is refused with `why`, never read out of bounds). What a blob does not carry
+// (layer names, source texts, arcs, modulation) is empty in the result.
+bool ir_deserialize(const uint8_t* data, size_t len, Ir& ir, std::string& why);
 
 // Whole-source entry point (lib.rs:117 up to and including codegen::generate's validation).
 struct CompiledProgram {

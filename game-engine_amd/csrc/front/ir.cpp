@@ -834,9 +834,191 @@ std::vector<uint8_t> ir_serialize(const Ir& ir)
     put_f32(b, ir.project.fov_deg);
     put_u32(b, ir.project.count);
     put_u32(b, 0);
+    // trailing section: the frame-level programs of expression-valued stage arguments (what game_ir_eval_derived runs)
+    put_u32(b, (uint32_t)ir.derived.size());
+    for (const IrDerived& d : ir.derived) {
+        put_u32(b, (uint32_t)d.prog.size());
+        for (const IrLawOp& o : d.prog) {
+            put_u32(b, o.op);
+            put_f32(b, o.val);
+            put_u32(b, o.fn);
+            put_u32(b, 0);
+        }
+    }
     uint32_t total = (uint32_t)b.size();
     for (int i = 0; i < 4; ++i) b[4 + i] = (uint8_t)(total >> (8 * i));
     return b;
+}
+
+// ── blob -> IR ───────────────────────────────────────────────────────────────────────────
+namespace {
+struct BlobReader {
+    const uint8_t* p; const uint8_t* end; bool ok = true;
+    uint32_t u32() { if (end - p < 4) { ok = false; return 0; } uint32_t v = (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; p += 4; return v; }
+    float f32() { uint32_t v = u32(); float f; memcpy(&f, &v, 4); return f; }
+    // fixed-width field holding a NUL-terminated string
+    std::string str(size_t n)
+    {
+        if ((size_t)(end - p) < n) { ok = false; return ""; }
+        const void* z = memchr(p, 0, n);
+        if (!z) { ok = false; p += n; return ""; }
+        std::string s((const char*)p, (const char*)z);
+        p += n;
+        return s;
+    }
+};
+bool finite32(float f) { return f - f == 0.0f; }
+
+// A reverse Polish program is usable when every operation is known, finds its operands on the stack, the stack stays
+// within the evaluators' depth and exactly the result is what is left on top. frame_floats: slots of a frame row it may
+// read (0 = none, a gravity force law); pixel: it may read p / uv.
+bool prog_well_formed(const std::vector<IrLawOp>& prog, uint32_t frame_floats, bool pixel, bool gravity)
+{
+    int sp = 0;
+    for (const IrLawOp& o : prog) {
+        int need = 0;
+        switch (o.op) {
+        case LAW_NUM: break;
+        case LAW_DIST: case LAW_TIME: if (!gravity) return false; break;   // the pair distance and the simulation time
+        case LAW_UNIFORM: if (o.fn >= frame_floats) return false; break;
+        case LAW_PX: case LAW_PY: case LAW_UVX: case LAW_UVY: if (!pixel) return false; break;
+        case LAW_ADD: case LAW_SUB: case LAW_MUL: case LAW_DIV: case LAW_POW: case LAW_GT: case LAW_LT: need = 2; break;
+        case LAW_NEG: need = 1; break;
+        // a call names a function of that many arguments
+        case LAW_CALL1: need = 1; if (!(o.fn <= LF_SIGN || (o.fn >= LF_EXP2 && o.fn <= LF_ROUND))) return false; break;
+        case LAW_CALL2: need = 2; if (!((o.fn >= LF_MIN && o.fn <= LF_STEP) || (o.fn >= LF_MOD && o.fn <= LF_LENGTH2))) return false; break;
+        case LAW_CALL3: need = 3; if (!(o.fn >= LF_CLAMP && o.fn <= LF_SMOOTHSTEP)) return false; break;
+        default: return false;
+        }
+        if (sp < need) return false;
+        sp = sp - need + 1;
+        if (sp > 60) return false;
+    }
+    return prog.empty() || sp >= 1;
+}
+
+bool read_prog(BlobReader& r, uint32_t n, std::vector<IrLawOp>& prog)
+{
+    prog.resize(n);
+    for (IrLawOp& o : prog) { o.op = r.u32(); o.val = r.f32(); o.fn = r.u32(); r.u32(); }
+    return r.ok;
+}
+}  // namespace
+
+bool ir_deserialize(const uint8_t* data, size_t len, Ir& ir, std::string& why)
+{
+    auto fail = [&](const char* m) { why = m; return false; };
+    ir = Ir{};
+    if (!data || len < 112) return fail("shorter than the header");
+    BlobReader r{data, data + len};
+    if (r.u32() != 0x31524947u) return fail("no 'GIR1' magic");
+    if (r.u32() != len) return fail("total_bytes does not match the length");
+    const uint32_t n_layers = r.u32(), n_stages = r.u32(), n_uniforms = r.u32(), n_law = r.u32();
+    if (n_layers > 4096 || n_stages > 65536 || n_uniforms > 4096 || n_law > 4096) return fail("a section count is beyond the format's limits");
+    ir.flags = r.u32();
+    ir.multi_layer = r.u32() != 0;
+    ir.uses_memory = r.u32() != 0;
+    ir.gravity.present = r.u32() != 0;
+    ir.gravity.damping = r.f32();
+    const uint32_t bounds = r.u32();
+    if (bounds > 2) return fail("unknown gravity bounds mode");
+    ir.gravity.bounds = (Bounds)bounds;
+    if (!finite32(ir.gravity.damping)) return fail("gravity damping is not finite");
+    ir.gravity.damping_text = fmt_f64_display((double)ir.gravity.damping);
+    ir.name = r.str(64);
+    if (!r.ok) return fail("cinematic name is not NUL-terminated");
+    bool any_memory = false;
+    ir.layers.resize(n_layers);
+    for (IrLayer& l : ir.layers) {
+        l.is_pipeline = r.u32() != 0;
+        l.stage_begin = r.u32();
+        l.stage_count = r.u32();
+        l.has_memory = r.u32() != 0;
+        l.decay = r.f32();
+        const uint32_t end_state = r.u32();
+        l.post = r.u32() != 0;
+        r.u32();
+        if (!r.ok) return fail("truncated in the layer table");
+        if ((uint64_t)l.stage_begin + l.stage_count > n_stages) return fail("a layer's stages lie outside the stage table");
+        if (end_state > 2) return fail("unknown layer end state");
+        if (!finite32(l.decay)) return fail("a memory decay is not finite");
+        l.end_state = (State)end_state;
+        l.decay_text = fmt_f64_display((double)l.decay);
+        any_memory = any_memory || (l.is_pipeline && l.has_memory);
+    }
+    if (any_memory != ir.uses_memory) return fail("uses_memory disagrees with the layers");
+    struct Packed { uint32_t v[4]; };
+    std::vector<Packed> packed(n_stages);
+    ir.stages.resize(n_stages);
+    for (uint32_t si = 0; si < n_stages; ++si) {
+        IrStage& s = ir.stages[si];
+        const uint32_t id = r.u32();
+        s.nargs = r.u32();
+        s.aux = r.u32();
+        r.u32();
+        for (int i = 0; i < 4; ++i) {
+            s.args[i].kind = r.u32();
+            s.args[i].slot = r.u32();
+            s.args[i].lit = r.f32();
+            packed[si].v[i] = r.u32();
+        }
+        if (!r.ok) return fail("truncated in the stage table");
+        const Builtin* b = id < builtin_count() ? builtin_by_id((uint16_t)id) : nullptr;
+        if (!b) return fail("unknown builtin id");
+        if (s.nargs > 4) return fail("a stage has more than four arguments");
+        s.builtin = (uint16_t)id;
+        s.name = b->name;
+        for (int i = 0; i < 4; ++i) {
+            const IrArg& a = s.args[i];
+            if (a.kind > ARG_BUILTIN) return fail("unknown stage argument kind");
+            if (a.kind == ARG_USER && a.slot >= n_uniforms) return fail("a stage argument names a user uniform that does not exist");
+            if (a.kind == ARG_BUILTIN && a.slot >= BU_COUNT) return fail("a stage argument names a built-in uniform that does not exist");
+            if (!finite32(a.lit)) return fail("a literal stage argument is not finite");
+        }
+    }
+    ir.uniforms.resize(n_uniforms);
+    for (UniformInfo& u : ir.uniforms) {
+        u.def = (double)r.f32();
+        u.name = r.str(60);
+        if (!r.ok) return fail("truncated or unterminated name in the uniform table");
+    }
+    if (!read_prog(r, n_law, ir.gravity.law)) return fail("truncated in the force law");
+    if (!prog_well_formed(ir.gravity.law, 0, false, true)) return fail("the force law is not a well-formed program");
+    const uint32_t frame_floats = BU_COUNT + n_uniforms;
+    const uint32_t n_pix = r.u32();
+    if (!r.ok || n_pix > 256) return fail("too many pixel expressions");
+    ir.pixel_exprs.resize(n_pix);
+    for (IrDerived& d : ir.pixel_exprs) {
+        const uint32_t n = r.u32();
+        if (!r.ok || n > 128 || !read_prog(r, n, d.prog)) return fail("truncated or oversized pixel expression");
+        if (d.prog.empty() || !prog_well_formed(d.prog, frame_floats, true, false)) return fail("a pixel expression is not a well-formed program");
+    }
+    const uint32_t pmode = r.u32();
+    ir.project.fov_deg = r.f32();
+    ir.project.count = r.u32();
+    r.u32();
+    if (!r.ok) return fail("truncated in the projection block");
+    if (pmode > 4) return fail("unknown projection mode");
+    ir.project.present = pmode != 0;
+    if (pmode) ir.project.mode = (ProjectMode)(pmode - 1);
+    if (!finite32(ir.project.fov_deg) || ir.project.count < 1 || ir.project.count > 1048576) return fail("projection parameters out of range");
+    const uint32_t n_derived = r.u32();
+    if (!r.ok || n_derived > 65535) return fail("too many derived values");
+    ir.derived.resize(n_derived);
+    for (IrDerived& d : ir.derived) {
+        const uint32_t n = r.u32();
+        if (!r.ok || n > 4096 || !read_prog(r, n, d.prog)) return fail("truncated or oversized derived-value program");
+        if (d.prog.empty() || !prog_well_formed(d.prog, frame_floats, false, false)) return fail("a derived value is not a well-formed program");
+    }
+    if (r.p != r.end) return fail("bytes left over after the last section");
+    for (uint32_t si = 0; si < n_stages; ++si)
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t lo = packed[si].v[i] & 0xffffu, hi = packed[si].v[i] >> 16;
+            if (lo > n_derived || hi > n_pix) return fail("a stage argument names an expression that does not exist");
+            ir.stages[si].args[i].derived = (int)lo - 1;
+            ir.stages[si].args[i].pixel = (int)hi - 1;
+        }
+    return true;
 }
 
 std::string ir_to_json(const Ir& ir)

@@ -22,6 +22,15 @@ std::string float_literal(float v)
 
 namespace {
 
+// A cinematic's name inside a `//` comment of the generated source: a line break would end the comment and a trailing
+// backslash would splice the next line into it, so anything but plain printable characters becomes '?'.
+std::string comment_safe(const std::string& name)
+{
+    std::string o = name;
+    for (char& c : o) if ((unsigned char)c < 0x20 || (unsigned char)c > 0x7e || c == '\\') c = '?';
+    return o;
+}
+
 // Reverse Polish program -> one HIP expression over the device functions (f32, one rounding per operator).
 // gravity = true: the force law of a gravity block (variables `dist` and the simulation time, gravity.rs:10-41);
 // otherwise a stage-argument expression that reads the pixel (`p`, `uv`) and the frame row.
@@ -182,7 +191,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
 {
     std::string k;
     k.reserve(8192);
-    k += "// generated for cinematic \"" + ir.name + "\"\n";
+    k += "// generated for cinematic \"" + comment_safe(ir.name) + "\"\n";
     k += "#include \"game_device.h\"\n\n";
     k += "struct GameFrameParams {\n"
          "    gd_u32* out;\n"
@@ -452,7 +461,7 @@ static std::string gravity_kernel_body(const Ir& ir, const char* name, unsigned 
 std::string generate_gravity_kernel(const Ir& ir, bool fast)
 {
     std::string k;
-    k += "// generated gravity step for cinematic \"" + ir.name + "\"" + (fast ? " (fast arithmetic)" : "") + "\n";
+    k += "// generated gravity step for cinematic \"" + comment_safe(ir.name) + "\"" + (fast ? " (fast arithmetic)" : "") + "\n";
     k += "#include \"game_device.h\"\n\n";
     k += "#ifndef GD_GRAV_UNROLL\n#define GD_GRAV_UNROLL 8\n#endif\n";
     k += "\n";

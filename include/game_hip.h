@@ -179,8 +179,24 @@ enum {
  *   then   : n_pixel_expressions, and per expression its length and that many law ops (ops 14..18 push a frame-row
  *            slot (fn), p.x, p.y, uv.x, uv.y)
  *   then   : project: mode + 1 (0 = none; 1 flat, 2 dome, 3 cube, 4 led), fov_deg(f32), led count, 0     (16 bytes)
+ *   then   : n_derived_values, and per value its length and that many law ops (the frame-level programs of
+ *            expression-valued stage arguments: numbers, frame-row slots, operators and calls only)
+ * Law ops: 0 number(value), 1 dist, 2 simulation time (force laws only), 3 + 4 - 5 * 6 / 7 pow 8 > 9 <, 10 negate,
+ * 11 / 12 / 13 call of a 1 / 2 / 3 argument function fn (0 sin cos tan abs sqrt exp log floor ceil fract 10 sign |
+ * 11 min max pow 14 step | 15 clamp mix 17 smoothstep | 18 exp2 log2 20 round | 21 mod atan2 23 length(x, y)),
+ * 14 frame-row slot fn, 15..18 p.x p.y uv.x uv.y (pixel expressions only).
  * Built-in uniform slot 0 used as a stage argument means the shader's wrapped time
  * `fract(u_time / 120) * 120` (glsl.rs:56), not the raw u_time. */
+
+/* The resolved IR as data. A host that runs the reference's own lexer, parser and optimizer
+ * (game_compiler::compile up to codegen::generate's validation, game-compiler/src/lib.rs:117-141, codegen/mod.rs:110-141)
+ * writes what `generate` would have frozen into shader text - the pipe-chain stage sequence with its arguments, the
+ * uniform table (codegen/mod.rs:54-107), memory decay, force law - into the blob layout above and hands it over here
+ * instead of `.game` text. Every count, index, string and program in the blob is validated; a blob that fails is refused
+ * with GAME_E_ARGUMENT and a reason in game_last_error(). The program holds one cinematic (game_program_ir(p, 0));
+ * layer names, source texts, arcs and modulation are not part of the blob and are empty. game_ir_blob of the result
+ * returns the same bytes. */
+int game_ir_from_blob(const void* data, size_t len, game_program** out);
 
 /* ── GPU render path ───────────────────────────────────────────────────────────────────────
  * game_hip_create replaces GameRendererGL.init (runtime/helpers.rs:148-183): where the browser

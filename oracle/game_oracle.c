@@ -141,9 +141,24 @@ static int ir_open(const void* blob, size_t len, ir_view* v)
         v->pix[i] = (const ir_law*)p; p += (size_t)v->pix_len[i] * sizeof(ir_law);
     }
     /* trailing section: the projection block (mode + 1, fov_deg, led count, pad) */
-    if (p + 16 != end) return -1;
+    if (p + 20 > end) return -1;
     memcpy(&v->project_mode, p, 4); memcpy(&v->project_fov_deg, p + 4, 4); memcpy(&v->project_count, p + 8, 4);
     if (v->project_mode > 4) return -1;
+    p += 16;
+    /* trailing section: the frame-level programs of expression-valued stage arguments. Their values reach the
+     * interpreter through the frame rows, so the programs are only checked and skipped. */
+    uint32_t n_derived;
+    memcpy(&n_derived, p, 4); p += 4;
+    if (n_derived > 65535) return -1;
+    for (uint32_t i = 0; i < n_derived; i++) {
+        uint32_t n;
+        if (p + 4 > end) return -1;
+        memcpy(&n, p, 4); p += 4;
+        if (n > 4096 || (size_t)(end - p) < (size_t)n * sizeof(ir_law)) return -1;
+        if (!prog_ok((const ir_law*)p, n, BU_COUNT + h->n_uniforms, 0)) return -1;
+        p += (size_t)n * sizeof(ir_law);
+    }
+    if (p != end) return -1;
     return ir_validate(v);
 }
 

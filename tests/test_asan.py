@@ -1,7 +1,8 @@
 """AddressSanitizer + UndefinedBehaviorSanitizer pass over the host side: the front end and the kernel generator
 (`make -C game-engine_amd asan`, no HIP) run every .game file of the reference corpus (when the reference tree is
 present), the benchmark cinematics, the builtin gallery and the seeded generator of the parity fuzz test; the IR blobs
-they produce then go, damaged at random, through the oracle's blob reader (`make -C oracle asan`). Any out-of-bounds
+they produce then go, whole and damaged at random, through the library's own blob loader (game_ir_from_blob, then the
+kernel generators again) and through the oracle's blob reader (`make -C oracle asan`). Any out-of-bounds
 access, use after free or undefined operation aborts the binaries (-fno-sanitize-recover)."""
 import glob
 import os
@@ -50,8 +51,11 @@ def test_host_side_is_clean_under_sanitizers(binaries, tmp_path, game):
         for d in ("examples", "presets", "stdlib", "game-compiler/examples"):
             files += sorted(glob.glob(os.path.join(REFERENCE, d, "*.game")))
         libs = ["--lib", os.path.join(REFERENCE, "stdlib")]
-    out = run([driver, *libs, "--blobs", str(blobdir), *files])
+    # every blob the corpus produces also goes back in through game_ir_from_blob, whole and damaged 25 times
+    out = run([driver, *libs, "--blobs", str(blobdir), "--mutate", "25", "--seed", "20261111", *files])
     compiled = int(out.split(" files compiled")[0].split()[-1])
+    loaded, refused = int(out.split(" damaged blobs loaded")[0].split()[-1]), int(out.split(" refused, no fault")[0].split()[-1])
+    assert loaded > 0 and refused > 0 and loaded + refused >= 25 * (len(sources) - 8)
     assert compiled >= len(sources) - 8
     blobs = sorted(str(p) for p in blobdir.glob("*.gir"))
     assert len(blobs) >= len(sources) - 8          # library files compile to no cinematic at all

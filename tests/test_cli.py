@@ -41,6 +41,23 @@ def test_ir_and_builtins(tmp_path):
     assert len(lines) == 38 and lines[0] == "circle|Position|Sdf|radius"
 
 
+def test_ir_blob_out_and_back_in(tmp_path, game):
+    """`game ir FILE --out X.gir` writes the resolved-IR blob; every command that takes a .game file takes the blob too."""
+    f = tmp_path / "m.game"
+    f.write_text(C4_TRAILS)
+    gir = tmp_path / "m.gir"
+    assert run("ir", str(f), "--out", str(gir)).returncode == 0
+    assert gir.read_bytes() == game.compile(C4_TRAILS).cinematics[0].blob
+    r = run("ir", str(gir))
+    assert r.returncode == 0 and json.loads(r.stdout)[0]["uses_memory"] is True
+    a, b = run("kernel", str(f), "--out", str(tmp_path / "ka")), run("kernel", str(gir), "--out", str(tmp_path / "kb"))
+    assert a.returncode == 0 and a.stdout == b.stdout and "gb_memory_mix" in a.stdout
+    bad = tmp_path / "bad.gir"
+    bad.write_bytes(gir.read_bytes()[:-8])
+    r = run("ir", str(bad))
+    assert r.returncode == 1 and "game_ir_from_blob" in r.stderr
+
+
 def test_render_requires_backend_flag(tmp_path):
     f = tmp_path / "g.game"
     f.write_text(C1_HELLO)
@@ -121,6 +138,17 @@ def test_render_writes_frames_equal_to_the_library(tmp_path, game):
         assert data.startswith(header)
         rgb = np.frombuffer(data[len(header):], dtype=np.uint8).reshape(64, 96, 3)
         assert np.array_equal(rgb, want[k][..., :3])
+
+
+@pytest.mark.gpu
+def test_render_from_ir_blob_equals_render_from_source(tmp_path):
+    f, gir = tmp_path / "t.game", tmp_path / "t.gir"
+    f.write_text(C4_TRAILS)
+    assert run("ir", str(f), "--out", str(gir)).returncode == 0
+    for src, out in ((f, "s"), (gir, "b")):
+        assert run("render", str(src), "--hip", "--size", "80x48", "--frames", "4", "--out", str(tmp_path / out)).returncode == 0
+    for k in range(4):
+        assert (tmp_path / f"s_{k:05d}.ppm").read_bytes() == (tmp_path / f"b_{k:05d}.ppm").read_bytes()
 
 
 @pytest.mark.gpu
