@@ -66,6 +66,18 @@ __global__ __launch_bounds__(256) void rmw_stride(const u32x4* __restrict__ in, 
     }
 }
 
+// write-only: what the stateless cinematics do (4 B per pixel out, nothing in), WORK dependent fma per pixel
+template <int WORK>
+__global__ __launch_bounds__(256) void fill_flat(u32x4* __restrict__ out, size_t n, float k)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    u32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = work<WORK>((unsigned)(i * 4 + j), k);
+    out[i] = v;
+}
+
 template <typename F>
 static double time_us(F launch, int reps)
 {
@@ -104,6 +116,10 @@ int main()
     RUN_MULTI(0, 2) RUN_MULTI(0, 4) RUN_MULTI(64, 2) RUN_MULTI(64, 4)
 #define RUN_STRIDE(W, G) report("stride grid=" #G " work=" #W, time_us([&] { rmw_stride<W><<<G, 256>>>(a, b, n, 0.999f); std::swap(a, b); }, 9));
     RUN_STRIDE(0, 2048) RUN_STRIDE(0, 4096) RUN_STRIDE(0, 8192) RUN_STRIDE(64, 2048) RUN_STRIDE(64, 4096) RUN_STRIDE(64, 8192)
+    // write-only kernels over the same 8K frame (133 MB out): the ceiling of the stateless cinematics
+    auto report_w = [&](const char* name, double us) { printf("%-34s %8.2f us  %6.2f TB/s written %8.0f Mpixel/s\n", name, us, px * 4.0 / us / 1e6, px / us); fflush(stdout); };
+#define RUN_FILL(W) report_w("write-only 16B/lane work=" #W, time_us([&] { fill_flat<W><<<gflat, 256>>>(b, n, 0.999f); }, 9));
+    RUN_FILL(0) RUN_FILL(16) RUN_FILL(32) RUN_FILL(48) RUN_FILL(64) RUN_FILL(96)
     // write-only and read-only ends of the spectrum
     report("hipMemset (write only, x2 bytes)", 2.0 * time_us([&] { CK(hipMemsetAsync(b, 1, px * 4, 0)); }, 9));
     return 0;
