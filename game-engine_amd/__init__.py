@@ -160,11 +160,11 @@ class Cinematic:
 
     @property
     def name(self):
-        return lib.game_ir_name(self._h).decode()
+        return lib.game_ir_name(self._h).decode("utf-8", "replace")
 
     @property
     def ir(self):
-        return json.loads(lib.game_ir_json(self._h).decode())
+        return json.loads(lib.game_ir_json(self._h).decode("utf-8", "replace"))
 
     @property
     def blob(self):
@@ -175,7 +175,7 @@ class Cinematic:
     @property
     def uniforms(self):
         n = lib.game_ir_uniform_count(self._h)
-        return [(lib.game_ir_uniform_name(self._h, i).decode(), lib.game_ir_uniform_default(self._h, i)) for i in range(n)]
+        return [(lib.game_ir_uniform_name(self._h, i).decode("utf-8", "replace"), lib.game_ir_uniform_default(self._h, i)) for i in range(n)]
 
     @property
     def flags(self):
