@@ -297,6 +297,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     }
     if (reads_uv_length) k += "    gd_uv_length(s);\n";   // once per pixel, shared by every stage that reads length(uv)
     k += "    float fr = 0.0f, fg = 0.0f, fb = 0.0f, fa = 1.0f;\n";
+    std::string row_state;   // declarations that live across the rows of a lane, placed ahead of the row loop
     for (size_t li = 0; li < ir.layers.size(); ++li) {
         const IrLayer& L = ir.layers[li];
         if (!L.is_pipeline || L.end_state != State::Color) continue;
@@ -313,8 +314,22 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
         }
         k += "    {   // layer " + std::to_string(li) + "\n";
         k += "        s.px = s.uvx * aspect; s.py = s.uvy; s.sdf = 0.0f; s.r = s.g = s.b = s.a = 0.0f;\n";
-        for (uint32_t si = 0; si < L.stage_count; ++si)
-            k += "        " + stage_call(ir.stages[L.stage_begin + si], shape, ir) + "\n";
+        for (uint32_t si = 0; si < L.stage_count; ++si) {
+            const IrStage& st = ir.stages[L.stage_begin + si];
+            std::string text = stage_call(st, shape, ir);
+            // A domain_warp that opens the layer warps the pixel's own p, whose x half does not change along the lane's rows:
+            // it keeps its x-interpolated lattice values from row to row (gb_domain_warp_rows). Not when an argument reads
+            // the pixel, and not under a projection, which moves uv.x from row to row.
+            bool reads_pixel = false;
+            for (uint32_t ai = 0; ai < 4; ++ai) reads_pixel = reads_pixel || (shape.animate && st.args[ai].pixel >= 0);
+            if (si == 0 && st.builtin == B_DOMAIN_WARP && shape.rows_per_lane > 1 && shape.pixels_per_lane == 1 && !warp && !reads_pixel &&
+                text.compare(0, 17, "gb_domain_warp(s,") == 0 && text.size() > 2 && text.compare(text.size() - 2, 2, ");") == 0) {
+                const std::string cache = "warp_rows_" + std::to_string(li);
+                text = "gb_domain_warp_rows" + text.substr(14, text.size() - 16) + ", " + cache + ");";
+                row_state += "    GdWarpRows " + cache + "; gd_warp_rows_reset(" + cache + ");\n";
+            }
+            k += "        " + text + "\n";
+        }
         if (L.has_memory) k += "        gb_memory_mix(s, prev, " + float_literal(L.decay) + ");\n";
         if (ir.multi_layer) {
             k += "        fr = fr + s.r - fr * s.r; fg = fg + s.g - fg * s.g; fb = fb + s.b - fb * s.b; fa = 1.0f;\n";
@@ -352,7 +367,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
         if (!seen[n]) { seen[n] = true; loads += "    const float " + name + " = U[" + std::to_string(n) + "];\n"; }
         at += name.size();
     }
-    k.insert(uniform_loads_at, loads);
+    k.insert(uniform_loads_at, loads + row_state);
     return k;
 }
 

@@ -627,6 +627,37 @@ GD void gb_domain_warp(GdPix& s, float amount, float freq)                      
     gd_noise2_pair_lut(s.px * freq, s.py * freq, s.px * freq + 5.2f, s.py * freq + 1.3f, s.lut, n0, n1);
     s.px = s.px + n0 * amount; s.py = s.py + n1 * amount;
 }
+// domain_warp as the first stage of a layer, inside the loop over a lane's rows. The position is then the pixel's own
+// p: its x half, and with it the lattice column and the Hermite weight ux of both noise samples, is the same on every row
+// of the lane, and the lattice row changes once in hundreds of image rows. The two x-interpolated edge values of a cell
+// (mix(a, b, ux) and mix(c, d, ux)) are therefore kept from row to row and fetched again only when the sample enters
+// another lattice row; every value is computed by the same operations as in gb_domain_warp, so the result is the same.
+struct GdWarpRows { float iy0, iy1, lo0, hi0, lo1, hi1; };
+GD void gd_warp_rows_reset(GdWarpRows& k) { k.iy0 = k.iy1 = __builtin_nanf(""); k.lo0 = k.hi0 = k.lo1 = k.hi1 = 0.0f; }
+GD void gb_domain_warp_rows(GdPix& s, float amount, float freq, GdWarpRows& k)
+{
+#ifdef GD_NO_WARP_ROWS   // A/B measurements: the plain form
+    { float n0, n1; gd_noise2_pair_lut(s.px * freq, s.py * freq, s.px * freq + 5.2f, s.py * freq + 1.3f, s.lut, n0, n1); s.px = s.px + n0 * amount; s.py = s.py + n1 * amount; return; }
+#endif
+    GdCell ca = gd_cell(s.px * freq, s.py * freq), cb = gd_cell(s.px * freq + 5.2f, s.py * freq + 1.3f);
+    float n0, n1;
+    if (s.lut != nullptr && ca.ok && cb.ok) {
+        if (ca.iy != k.iy0) {
+            GdCorners c = gd_corners_load(ca, s.lut);
+            k.lo0 = gd_mix(c.a, c.b, ca.ux); k.hi0 = gd_mix(c.c, c.d, ca.ux); k.iy0 = ca.iy;
+        }
+        if (cb.iy != k.iy1) {
+            GdCorners c = gd_corners_load(cb, s.lut);
+            k.lo1 = gd_mix(c.a, c.b, cb.ux); k.hi1 = gd_mix(c.c, c.d, cb.ux); k.iy1 = cb.iy;
+        }
+        n0 = __builtin_fmaf(gd_mix(k.lo0, k.hi0, ca.uy), 2.0f, -1.0f);
+        n1 = __builtin_fmaf(gd_mix(k.lo1, k.hi1, cb.uy), 2.0f, -1.0f);
+    } else {
+        n0 = gd_noise2_combine(ca, gd_corners_hash(ca));
+        n1 = gd_noise2_combine(cb, gd_corners_hash(cb));
+    }
+    s.px = s.px + n0 * amount; s.py = s.py + n1 * amount;
+}
 GD void gb_curl_noise(GdPix& s, float frequency, float amplitude)                                       // :367-377
 {
     const float eps = 0.001f;
