@@ -217,7 +217,13 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     const std::string ppl = std::to_string(shape.pixels_per_lane);
     if (nvec > 1) k += "    const gd_u32 x0 = blockIdx.x * " + std::to_string(shape.wg * shape.pixels_per_lane) + "u + threadIdx.x * 4u;\n";
     else k += "    const gd_u32 x0 = (blockIdx.x * " + wg + "u + threadIdx.x) * " + ppl + "u;\n";
-    k += "    if (x0 >= P.w) return;\n";
+    // Several rows per lane: what a row needs from y alone (uv.y, and the y halves of a leading domain_warp's lattice
+    // samples) is the same for every lane of the workgroup, so lane r of the workgroup works it out for row r once, into
+    // shared memory, and the row loop reads it from there. The early return of lanes beyond the right edge then comes
+    // after the barrier.
+    const bool project_warp = shape.project && ir.project.present && (ir.project.mode == ProjectMode::Dome || ir.project.mode == ProjectMode::Led);
+    const bool row_lds = shape.row_shared && shape.rows_per_lane > 1 && !project_warp && shape.wg >= shape.rows_per_lane;
+    if (!row_lds) k += "    if (x0 >= P.w) return;\n";
     // The uniform row is read through the constant address space: nothing writes it while the kernel runs, so its
     // loads are scalar and invariant. Every slot the pipeline reads is loaded here, ahead of the row loop, so that
     // whatever is computed from uniforms and the column alone leaves the loop with them.
@@ -243,8 +249,12 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     k += "    s.time = U[" + std::to_string(shape.time_slot) + "];\n";
     k += "    const float aspect = U[" + std::to_string(shape.aspect_slot) + "];\n";
     k += "    s.bass = U[1]; s.mid = U[2]; s.treble = U[3];\n";
-    k += "    const float vy = ((float)(P.h - 1u - ty) + 0.5f) * P.inv_h;\n";   // GL row 0 is the bottom row
-    k += "    s.uvy = vy * 2.0f - 1.0f;\n";
+    if (row_lds) {
+        k += "    s.uvy = gd_rowv[ry * GD_ROWV];\n";
+    } else {
+        k += "    const float vy = ((float)(P.h - 1u - ty) + 0.5f) * P.inv_h;\n";   // GL row 0 is the bottom row
+        k += "    s.uvy = vy * 2.0f - 1.0f;\n";
+    }
     if (nvec > 1) {
         const std::string nv = std::to_string(nvec);
         if (ir.uses_memory) {
@@ -298,6 +308,8 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     if (reads_uv_length) k += "    gd_uv_length(s);\n";   // once per pixel, shared by every stage that reads length(uv)
     k += "    float fr = 0.0f, fg = 0.0f, fb = 0.0f, fa = 1.0f;\n";
     std::string row_state;   // declarations that live across the rows of a lane, placed ahead of the row loop
+    std::string row_prologue;   // what lane r of the workgroup stores for row r besides uv.y
+    uint32_t row_caches = 0;
     for (size_t li = 0; li < ir.layers.size(); ++li) {
         const IrLayer& L = ir.layers[li];
         if (!L.is_pipeline || L.end_state != State::Color) continue;
@@ -322,11 +334,16 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
             // the pixel, and not under a projection, which moves uv.x from row to row.
             bool reads_pixel = false;
             for (uint32_t ai = 0; ai < 4; ++ai) reads_pixel = reads_pixel || (shape.animate && st.args[ai].pixel >= 0);
-            if (si == 0 && st.builtin == B_DOMAIN_WARP && shape.rows_per_lane > 1 && shape.pixels_per_lane == 1 && !warp && !reads_pixel &&
+            const size_t comma = text.rfind(", ");
+            if (si == 0 && st.builtin == B_DOMAIN_WARP && row_lds && shape.pixels_per_lane == 1 && !reads_pixel && comma != std::string::npos &&
                 text.compare(0, 17, "gb_domain_warp(s,") == 0 && text.size() > 2 && text.compare(text.size() - 2, 2, ");") == 0) {
                 const std::string cache = "warp_rows_" + std::to_string(li);
-                text = "gb_domain_warp_rows" + text.substr(14, text.size() - 16) + ", " + cache + ");";
+                const std::string freq = text.substr(comma + 2, text.size() - 2 - (comma + 2));     // the second argument as written
+                const std::string at = std::to_string(4u + 8u * row_caches);
+                text = "gb_domain_warp_rows" + text.substr(14, text.size() - 16) + ", " + cache + ", *(const GdWarpY*)&gd_rowv[ry * GD_ROWV + " + at + "]);";
                 row_state += "    GdWarpRows " + cache + "; gd_warp_rows_reset(" + cache + ");\n";
+                row_prologue += "        gd_warp_rows_y(uvy, " + freq + ", &gd_rowv[threadIdx.x * GD_ROWV + " + at + "]);\n";
+                ++row_caches;
             }
             k += "        " + text + "\n";
         }
@@ -367,7 +384,20 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
         if (!seen[n]) { seen[n] = true; loads += "    const float " + name + " = U[" + std::to_string(n) + "];\n"; }
         at += name.size();
     }
-    k.insert(uniform_loads_at, loads + row_state);
+    std::string shared;
+    if (row_lds) {
+        const std::string rowv = std::to_string(4u + 8u * row_caches);
+        shared += "#define GD_ROWV " + rowv + "u\n";
+        shared += "    __shared__ __attribute__((aligned(16))) float gd_rowv[" + rpl + " * GD_ROWV];\n";
+        shared += "    if (threadIdx.x < " + rpl + "u) {\n";
+        shared += "        const gd_u32 ty = P.row0 + blockIdx.y * " + rpl + "u + threadIdx.x;\n";
+        shared += "        const float vy = ((float)(P.h - 1u - ty) + 0.5f) * P.inv_h;\n";   // GL row 0 is the bottom row
+        shared += "        const float uvy = vy * 2.0f - 1.0f;\n";
+        shared += "        gd_rowv[threadIdx.x * GD_ROWV] = uvy;\n";
+        shared += row_prologue;
+        shared += "    }\n    __syncthreads();\n    if (x0 >= P.w) return;\n";
+    }
+    k.insert(uniform_loads_at, loads + shared + row_state);
     return k;
 }
 

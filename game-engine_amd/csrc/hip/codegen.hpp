@@ -16,6 +16,7 @@ struct KernelShape {
     bool lens_post = false;         // run the lens post chain on the composited colour
     bool project = false;           // apply the cinematic's projection block (Ir::project) to v_uv
     uint32_t wg = 256;              // threads per workgroup (a multiple of 64)
+    bool row_shared = true;         // with several rows per lane: per-row values worked out once per workgroup, in shared memory
 };
 
 std::string float_literal(float v);

@@ -628,30 +628,49 @@ GD void gb_domain_warp(GdPix& s, float amount, float freq)                      
     s.px = s.px + n0 * amount; s.py = s.py + n1 * amount;
 }
 // domain_warp as the first stage of a layer, inside the loop over a lane's rows. The position is then the pixel's own
-// p: its x half, and with it the lattice column and the Hermite weight ux of both noise samples, is the same on every row
-// of the lane, and the lattice row changes once in hundreds of image rows. The two x-interpolated edge values of a cell
-// (mix(a, b, ux) and mix(c, d, ux)) are therefore kept from row to row and fetched again only when the sample enters
-// another lattice row; every value is computed by the same operations as in gb_domain_warp, so the result is the same.
+// p. Its x half, and with it the lattice column and the Hermite weight ux of both noise samples, is the same on every row
+// of the lane; its y half is the same for every lane of the workgroup, so one lane per row works it out once
+// (gd_warp_rows_y, into shared memory) and the others read it; and the lattice row changes once in hundreds of image
+// rows, so the two x-interpolated edge values of a cell (mix(a, b, ux) and mix(c, d, ux)) are kept from row to row and
+// fetched again only when the sample enters another lattice row. Every value is computed by the same operations as in
+// gb_domain_warp, so the result is the same.
 struct GdWarpRows { float iy0, iy1, lo0, hi0, lo1, hi1; };
+struct __attribute__((aligned(16))) GdWarpY { float iy0, uy0, om0, iy1, uy1, om1, ok, pad; };   // y halves of both samples; om = 1 - uy
 GD void gd_warp_rows_reset(GdWarpRows& k) { k.iy0 = k.iy1 = __builtin_nanf(""); k.lo0 = k.hi0 = k.lo1 = k.hi1 = 0.0f; }
-GD void gb_domain_warp_rows(GdPix& s, float amount, float freq, GdWarpRows& k)
+GD void gd_warp_rows_y(float py, float freq, float* o)
+{
+    const float a = py * freq, b = py * freq + 1.3f;
+    const float iy0 = gd_floor(a), f0 = gd_fract(a), iy1 = gd_floor(b), f1 = gd_fract(b);
+    const float uy0 = f0 * f0 * __builtin_fmaf(-2.0f, f0, 3.0f), uy1 = f1 * f1 * __builtin_fmaf(-2.0f, f1, 3.0f);
+    o[0] = iy0; o[1] = uy0; o[2] = 1.0f - uy0;
+    o[3] = iy1; o[4] = uy1; o[5] = 1.0f - uy1;
+    o[6] = (gd_abs(iy0) <= 511.0f && gd_abs(iy1) <= 511.0f) ? 1.0f : 0.0f;
+    o[7] = 0.0f;
+}
+GD void gb_domain_warp_rows(GdPix& s, float amount, float freq, GdWarpRows& k, const GdWarpY& y)
 {
 #ifdef GD_NO_WARP_ROWS   // A/B measurements: the plain form
     { float n0, n1; gd_noise2_pair_lut(s.px * freq, s.py * freq, s.px * freq + 5.2f, s.py * freq + 1.3f, s.lut, n0, n1); s.px = s.px + n0 * amount; s.py = s.py + n1 * amount; return; }
 #endif
-    GdCell ca = gd_cell(s.px * freq, s.py * freq), cb = gd_cell(s.px * freq + 5.2f, s.py * freq + 1.3f);
+    const float ax = s.px * freq, bx = s.px * freq + 5.2f;
+    const float fa = gd_fract(ax), fb = gd_fract(bx);
+    GdCell ca, cb;
+    ca.ix = gd_floor(ax); ca.ux = fa * fa * __builtin_fmaf(-2.0f, fa, 3.0f); ca.iy = y.iy0; ca.uy = y.uy0;
+    cb.ix = gd_floor(bx); cb.ux = fb * fb * __builtin_fmaf(-2.0f, fb, 3.0f); cb.iy = y.iy1; cb.uy = y.uy1;
     float n0, n1;
-    if (s.lut != nullptr && ca.ok && cb.ok) {
+    if (s.lut != nullptr && gd_abs(ca.ix) <= 511.0f && gd_abs(cb.ix) <= 511.0f && y.ok != 0.0f) {
         if (ca.iy != k.iy0) {
+            ca.off = gd_lut_offset(ca.ix, ca.iy, 0.0f);
             GdCorners c = gd_corners_load(ca, s.lut);
             k.lo0 = gd_mix(c.a, c.b, ca.ux); k.hi0 = gd_mix(c.c, c.d, ca.ux); k.iy0 = ca.iy;
         }
         if (cb.iy != k.iy1) {
+            cb.off = gd_lut_offset(cb.ix, cb.iy, 0.0f);
             GdCorners c = gd_corners_load(cb, s.lut);
             k.lo1 = gd_mix(c.a, c.b, cb.ux); k.hi1 = gd_mix(c.c, c.d, cb.ux); k.iy1 = cb.iy;
         }
-        n0 = __builtin_fmaf(gd_mix(k.lo0, k.hi0, ca.uy), 2.0f, -1.0f);
-        n1 = __builtin_fmaf(gd_mix(k.lo1, k.hi1, cb.uy), 2.0f, -1.0f);
+        n0 = __builtin_fmaf(__builtin_fmaf(k.hi0, y.uy0, k.lo0 * y.om0), 2.0f, -1.0f);   // mix(lo, hi, uy) * 2 - 1
+        n1 = __builtin_fmaf(__builtin_fmaf(k.hi1, y.uy1, k.lo1 * y.om1), 2.0f, -1.0f);
     } else {
         n0 = gd_noise2_combine(ca, gd_corners_hash(ca));
         n1 = gd_noise2_combine(cb, gd_corners_hash(cb));

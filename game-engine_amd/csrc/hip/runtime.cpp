@@ -241,6 +241,7 @@ KernelShape shape_for(const Ir& ir, uint32_t width, uint32_t flags = 0)
         int v = atoi(e);
         if (v >= 1 && v <= 64) s.rows_per_lane = (uint32_t)v;
     }
+    if (const char* e = getenv("GAME_HIP_ROWLDS")) s.row_shared = atoi(e) != 0;   // tuning hook
     if (const char* e = getenv("GAME_HIP_WG")) {    // tuning hook
         int v = atoi(e);
         if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) s.wg = (uint32_t)v;
