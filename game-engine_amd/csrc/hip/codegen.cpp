@@ -338,7 +338,8 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
             if (si == 0 && st.builtin == B_DOMAIN_WARP && row_lds && shape.pixels_per_lane == 1 && !reads_pixel && comma != std::string::npos &&
                 text.compare(0, 17, "gb_domain_warp(s,") == 0 && text.size() > 2 && text.compare(text.size() - 2, 2, ");") == 0) {
                 const std::string cache = "warp_rows_" + std::to_string(li);
-                const std::string freq = text.substr(comma + 2, text.size() - 2 - (comma + 2));     // the second argument as written
+                std::string freq = text.substr(comma + 2, text.size() - 2 - (comma + 2));     // the second argument as written
+                if (freq == "s.time") freq = "U[" + std::to_string(shape.time_slot) + "]";          // ahead of the loop there is no `s` yet
                 const std::string at = std::to_string(4u + 8u * row_caches);
                 text = "gb_domain_warp_rows" + text.substr(14, text.size() - 16) + ", " + cache + ", *(const GdWarpY*)&gd_rowv[ry * GD_ROWV + " + at + "]);";
                 row_state += "    GdWarpRows " + cache + "; gd_warp_rows_reset(" + cache + ");\n";

@@ -171,20 +171,22 @@ def test_c2_fbm_showcase(game, oracle, w, h):
 
 
 @pytest.mark.parametrize("warp", ["domain_warp(0.3, 40.0)", "domain_warp(0.2, 300.0)", "domain_warp(0.1, knob)", "domain_warp(0.1 + p.y, 3.0)",
-                                  "domain_warp(-0.0, 0.0)", "domain_warp(1000000.0, 0.000001)"],
-                         ids=["fine-lattice", "leaves-table", "uniform-frequency", "pixel-argument", "zero", "extreme"])
+                                  "domain_warp(-0.0, 0.0)", "domain_warp(1000000.0, 0.000001)", "domain_warp(0.2, time)",
+                                  "domain_warp(0.2, 2.0 + sin(time) * 30.0)"],
+                         ids=["fine-lattice", "leaves-table", "uniform-frequency", "pixel-argument", "zero", "extreme", "time-frequency",
+                              "expression-frequency"])
 def test_domain_warp_across_lattice_rows(game, oracle, warp):
     """A domain_warp that opens a layer keeps its x-interpolated lattice values from one row of a lane to the next and
     fetches again when the sample enters another lattice row: frames tall enough that every lane crosses many lattice
     rows, frequencies whose cells leave the hash table on part of the frame (the arithmetic path in between table
-    rows), a frequency from a uniform that changes per frame, an argument that reads the pixel (which must take the plain
+    rows), a frequency from a uniform, from the shader's time and from a per-frame expression, an argument that reads the pixel (which must take the plain
     form), bands that start inside a lane's run of rows, both wordings."""
     src = 'cinematic "w" { layer a { fn: %s | fbm(2.0, octaves: 2) | glow(1.5) } layer b { fn: %s | circle(0.4) | glow(2.0) | tint(0.2, 0.5, 1.0) } }' % (warp, warp)
     cin = game.compile(src).cinematics[0]
     w, h = 48, 531
-    rows = cin.uniform_rows([0.0, 0.4], w, h, user={"knob": [7.0, 23.5]} if "knob" in warp else None)
+    rows = cin.uniform_rows([0.0, 7.4], w, h, user={"knob": [7.0, 23.5]} if "knob" in warp else None)
     for sem in ("glsl", "wgsl"):
-        animate = "p.y" in warp
+        animate = "p.y" in warp or "sin(" in warp
         r = cin.renderer(w, h, semantics=sem, animate=animate)
         got = r.render(rows)
         want = oracle.render_sequence(cin.blob, w, h, rows, False, semantics=sem, derived=cin.eval_derived(rows) if animate else None, animate=animate)
