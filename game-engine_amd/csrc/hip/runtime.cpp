@@ -208,7 +208,7 @@ bool uses_lattice_noise(const Ir& ir)
 // frame store (and the previous-frame load): four pixels per lane turn those into 16-byte accesses.
 // Noise-heavy cinematics are bound by VALU issue and keep one pixel per lane (fewest registers,
 // no unrolled copies of a long body). Rows stay 16-byte aligned only when the width is a multiple of 4.
-KernelShape shape_for(const Ir& ir, uint32_t width, uint32_t flags = 0)
+KernelShape shape_for(const Ir& ir, uint32_t width, uint32_t height, uint32_t flags = 0)
 {
     KernelShape s;
     s.wgsl = (flags & GAME_HIP_SEMANTICS_WGSL) != 0;
@@ -236,6 +236,11 @@ KernelShape shape_for(const Ir& ir, uint32_t width, uint32_t flags = 0)
         for (const IrLayer& L : ir.layers)
             if (L.is_pipeline && L.stage_count && ir.stages[L.stage_begin].builtin == B_SPECTRUM) column_first = true;
         s.rows_per_lane = (heavy || column_first) ? 8u : 4u;
+        // Noise cinematics gain from longer runs of rows: what a lane keeps across rows (the lattice values of a leading
+        // domain_warp, everything computed from the column) is paid for once per run, and the per-row values of the
+        // workgroup once per 32 rows. c2 at 4K: +6 % at 32 rows over 8, +7 % at 64. Frames need the height for it: a
+        // 2160-row frame still has 68 workgroup rows at 32.
+        if (heavy) s.rows_per_lane = height >= 1024u ? 32u : height >= 512u ? 16u : 8u;
     }
     if (const char* e = getenv("GAME_HIP_RPL")) {   // tuning hook
         int v = atoi(e);
@@ -472,7 +477,7 @@ int game_hip_compile_only_ex(const game_ir* ir, uint32_t flags, size_t* code_byt
 {
     if (!ir) return set_error(GAME_E_ARGUMENT, "game_hip_compile_only: null ir");
     std::vector<char> code;
-    std::string src = generate_frame_kernel(*ir->ir, shape_for(*ir->ir, 3840u, flags));
+    std::string src = generate_frame_kernel(*ir->ir, shape_for(*ir->ir, 3840u, 2160u, flags));
     int rc = compile_hip(src, "game_frame.hip", code);
     if (rc) return rc;
     size_t total = code.size();
@@ -496,7 +501,7 @@ int game_hip_dump_code(const game_ir* ir, const char* path_prefix)
         return ok;
     };
     std::vector<char> code;
-    std::string src = generate_frame_kernel(*ir->ir, shape_for(*ir->ir, 3840u));
+    std::string src = generate_frame_kernel(*ir->ir, shape_for(*ir->ir, 3840u, 2160u));
     int rc = compile_hip(src, "game_frame.hip", code);
     if (rc) return rc;
     std::string pre(path_prefix);
@@ -536,7 +541,7 @@ int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int d
     c->ir = *ir->ir;
     c->device = device;
     c->w = width; c->h = height;
-    c->shape = shape_for(c->ir, c->w, flags);
+    c->shape = shape_for(c->ir, c->w, c->h, flags);
     if (const char* e = getenv("GAME_HIP_LDS_BYTES")) c->lds_bytes = (unsigned)atoi(e);   // tuning hook, read per context
     c->row_floats = BU_COUNT + (uint32_t)c->ir.uniforms.size();
     c->ustride = c->row_floats + 2 + (c->shape.animate ? (uint32_t)c->ir.derived.size() : 0u);
