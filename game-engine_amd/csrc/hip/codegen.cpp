@@ -309,7 +309,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     k += "    float fr = 0.0f, fg = 0.0f, fb = 0.0f, fa = 1.0f;\n";
     std::string row_state;   // declarations that live across the rows of a lane, placed ahead of the row loop
     std::string row_prologue;   // what lane r of the workgroup stores for row r besides uv.y
-    uint32_t row_caches = 0;
+    uint32_t row_floats = 4;     // uv.y and padding first
     for (size_t li = 0; li < ir.layers.size(); ++li) {
         const IrLayer& L = ir.layers[li];
         if (!L.is_pipeline || L.end_state != State::Color) continue;
@@ -334,17 +334,39 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
             // the pixel, and not under a projection, which moves uv.x from row to row.
             bool reads_pixel = false;
             for (uint32_t ai = 0; ai < 4; ++ai) reads_pixel = reads_pixel || (shape.animate && st.args[ai].pixel >= 0);
-            const size_t comma = text.rfind(", ");
-            if (si == 0 && st.builtin == B_DOMAIN_WARP && row_lds && shape.pixels_per_lane == 1 && !reads_pixel && comma != std::string::npos &&
-                text.compare(0, 17, "gb_domain_warp(s,") == 0 && text.size() > 2 && text.compare(text.size() - 2, 2, ");") == 0) {
-                const std::string cache = "warp_rows_" + std::to_string(li);
-                std::string freq = text.substr(comma + 2, text.size() - 2 - (comma + 2));     // the second argument as written
-                if (freq == "s.time") freq = "U[" + std::to_string(shape.time_slot) + "]";          // ahead of the loop there is no `s` yet
-                const std::string at = std::to_string(4u + 8u * row_caches);
-                text = "gb_domain_warp_rows" + text.substr(14, text.size() - 16) + ", " + cache + ", *(const GdWarpY*)&gd_rowv[ry * GD_ROWV + " + at + "]);";
-                row_state += "    GdWarpRows " + cache + "; gd_warp_rows_reset(" + cache + ");\n";
-                row_prologue += "        gd_warp_rows_y(uvy, " + freq + ", &gd_rowv[threadIdx.x * GD_ROWV + " + at + "]);\n";
-                ++row_caches;
+            // split "gb_name(s, a, b, ...);" into its name and arguments as written
+            std::vector<std::string> av;
+            const size_t open = text.find("(s, ");
+            if (si == 0 && row_lds && shape.pixels_per_lane == 1 && !reads_pixel && open != std::string::npos && text.size() > open + 6 &&
+                text.compare(text.size() - 2, 2, ");") == 0) {
+                const std::string inner = text.substr(open + 4, text.size() - 2 - (open + 4));
+                for (size_t b = 0; b <= inner.size();) {
+                    const size_t e = inner.find(", ", b);
+                    av.push_back(inner.substr(b, e == std::string::npos ? std::string::npos : e - b));
+                    if (e == std::string::npos) break;
+                    b = e + 2;
+                }
+            }
+            // kind of cache, its y-prologue function, floats it takes in the workgroup's row values, index of the argument the
+            // y half is scaled by
+            const char* kind = nullptr; const char* type = nullptr; uint32_t floats = 0; size_t yarg = 0;
+            if (!av.empty()) {
+                if (st.builtin == B_DOMAIN_WARP && av.size() == 2) { kind = "warp"; type = "GdWarpRows"; floats = 8; yarg = 1; }
+                else if (st.builtin == B_VORONOI && !shape.wgsl && av.size() == 1) { kind = "voronoi"; type = "GdVoronoiRows"; floats = 4; yarg = 0; }
+                else if (st.builtin == B_FBM && av.size() == 4 && st.args[1].kind == ARG_LIT && octaves_of(st.args[1].lit) >= 1 &&
+                         octaves_of(st.args[1].lit) <= 8) { kind = "fbm"; type = "GdFbmRows"; floats = 4; yarg = 0; }
+            }
+            if (kind) {
+                const std::string cache = std::string(kind) + "_rows_" + std::to_string(li);
+                std::string scale = av[yarg];
+                if (scale == "s.time") scale = "U[" + std::to_string(shape.time_slot) + "]";          // ahead of the loop there is no `s` yet
+                const std::string at = std::to_string(row_floats);
+                const std::string rowp = "&gd_rowv[ry * GD_ROWV + " + at + "]";
+                text = "gb_" + (st.builtin == B_DOMAIN_WARP ? std::string("domain_warp") : std::string(kind)) + "_rows" + text.substr(open, text.size() - 2 - open) + ", " + cache + ", " +
+                       (st.builtin == B_DOMAIN_WARP ? "*(const GdWarpY*)" + rowp : rowp) + ");";
+                row_state += "    " + std::string(type) + " " + cache + "; gd_" + kind + "_rows_reset(" + cache + ");\n";
+                row_prologue += "        gd_" + std::string(kind) + "_rows_y(uvy, " + scale + ", &gd_rowv[threadIdx.x * GD_ROWV + " + at + "]);\n";
+                row_floats += floats;
             }
             k += "        " + text + "\n";
         }
@@ -387,7 +409,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     }
     std::string shared;
     if (row_lds) {
-        const std::string rowv = std::to_string(4u + 8u * row_caches);
+        const std::string rowv = std::to_string(row_floats);
         shared += "#define GD_ROWV " + rowv + "u\n";
         shared += "    __shared__ __attribute__((aligned(16))) float gd_rowv[" + rpl + " * GD_ROWV];\n";
         shared += "    if (threadIdx.x < " + rpl + "u) {\n";

@@ -677,6 +677,112 @@ GD void gb_domain_warp_rows(GdPix& s, float amount, float freq, GdWarpRows& k, c
     }
     s.px = s.px + n0 * amount; s.py = s.py + n1 * amount;
 }
+// voronoi and fbm as the first stage of a layer get the same treatment (c2b: the three layers of tutorial-05-noise).
+// voronoi: the nine feature points of the 3 x 3 block change only with the lattice row, and of a candidate's squared
+// distance (nx + hx - fx)^2 + (ny + hy - fy)^2 the first square and ny + hy do not depend on the image row at all.
+struct GdVoronoiRows { float iy; float px2[9]; float nyh[9]; };
+GD void gd_voronoi_rows_reset(GdVoronoiRows& k)
+{
+    k.iy = __builtin_nanf("");
+#pragma unroll
+    for (int i = 0; i < 9; i++) k.px2[i] = k.nyh[i] = 0.0f;
+}
+GD void gd_voronoi_rows_y(float py, float scale, float* o)   // {floor, fract, inside the table, -}
+{
+    const float psy = py * scale;
+    o[0] = gd_floor(psy); o[1] = gd_fract(psy); o[2] = gd_abs(o[0]) <= 510.0f ? 1.0f : 0.0f; o[3] = 0.0f;
+}
+GD void gb_voronoi_rows(GdPix& s, float scale, GdVoronoiRows& k, const float* y)
+{
+    const float psx = s.px * scale;
+    const float ipx = gd_floor(psx), fpx = gd_fract(psx);
+    const float ipy = y[0], fpy = y[1];
+    if (!(s.vlut != nullptr && gd_abs(ipx) <= 510.0f && y[2] != 0.0f)) { s.sdf = gd_voronoi2d(s.px, s.py, scale); return; }
+    if (ipy != k.iy) {
+        const char* base = (const char*)s.vlut + gd_lut_offset(ipx, ipy, -1.0f);   // entry (ipy - 1, ipx - 1)
+#pragma unroll
+        for (int yy = -1; yy <= 1; yy++) {
+            const char* row = base + (gd_u32)(yy + 1) * (GD_LUT_STRIDE * 8u);
+            gd_f32x4_a8 e01 = *(const gd_f32x4_a8*)row;
+            gd_f32x2 e2 = *(const gd_f32x2*)(row + 16);
+            float hx[3] = {e01[0], e01[2], e2[0]}, hy[3] = {e01[1], e01[3], e2[1]};
+#pragma unroll
+            for (int xx = -1; xx <= 1; xx++) {
+                const float nx = (float)xx, ny = (float)yy;
+                const float ptx = nx + hx[xx + 1] - fpx;
+                k.px2[(yy + 1) * 3 + xx + 1] = ptx * ptx;
+                k.nyh[(yy + 1) * 3 + xx + 1] = ny + hy[xx + 1];
+            }
+        }
+        k.iy = ipy;
+    }
+    float d = 1.0f;
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        const float pty = k.nyh[c] - fpy;
+        d = gd_min(d, k.px2[c] + pty * pty);
+    }
+    s.sdf = gd_sqrt(d);
+}
+// fbm with a literal octave count: octave 0 samples at p * scale itself (the rotation starts with octave 1), so its
+// lattice column, its x weight and - from row to row - its x-interpolated edge values stay.
+struct GdFbmRows { float iy, lo, hi; };
+GD void gd_fbm_rows_reset(GdFbmRows& k) { k.iy = __builtin_nanf(""); k.lo = k.hi = 0.0f; }
+GD void gd_fbm_rows_y(float py, float scale, float* o)   // {lattice row, uy, 1 - uy, -} of octave 0
+{
+    const float a = py * scale;
+    const float f = gd_fract(a);
+    o[0] = gd_floor(a); o[1] = f * f * __builtin_fmaf(-2.0f, f, 3.0f); o[2] = 1.0f - o[1]; o[3] = 0.0f;
+}
+GD void gb_fbm_rows(GdPix& s, float scale, int octaves, float persistence, float lacunarity, GdFbmRows& k, const float* y)
+{
+    const float px = s.px * scale, py = s.py * scale;
+    if (!(s.lut != nullptr && __builtin_constant_p(octaves) && octaves >= 1 && octaves <= 8)) {
+        s.sdf = gd_fbm2(px, py, octaves, persistence, lacunarity, s.lut);
+        return;
+    }
+    // as gd_fbm2's table path; cell 0 takes its y half from the workgroup's row values
+    GdCell cell[8];
+    float amp[8];
+    float amplitude = 1.0f, frequency = 1.0f, max_val = 0.0f, qx = px, qy = py, fmax = 1.0f;
+#pragma unroll
+    for (int i = 0; i < octaves; i++) {
+        if (i == 0) {
+            const float fx = gd_fract(qx * frequency);
+            cell[0].ix = gd_floor(qx * frequency); cell[0].iy = y[0];
+            cell[0].ux = fx * fx * __builtin_fmaf(-2.0f, fx, 3.0f); cell[0].uy = y[1];
+        } else {
+            cell[i] = gd_cell(qx * frequency, qy * frequency);
+        }
+        fmax = !(gd_abs(frequency) <= fmax) ? gd_abs(frequency) : fmax;
+        amp[i] = amplitude;
+        max_val = max_val + amplitude;
+        amplitude = amplitude * persistence;
+        frequency = frequency * lacunarity;
+        float nx = __builtin_fmaf(qx, 0.8f, -(qy * 0.6f));
+        float ny = __builtin_fmaf(qx, 0.6f, qy * 0.8f);
+        qx = nx; qy = ny;
+    }
+    const bool ok = __builtin_fmaf(px, px, py * py) * (fmax * fmax) <= 259081.0f;
+    float value = 0.0f;
+    if (ok) {
+        GdCorners c[8];
+#pragma unroll
+        for (int i = 1; i < octaves; i++) c[i] = gd_corners_load(cell[i], s.lut);
+        if (cell[0].iy != k.iy) {
+            cell[0].off = gd_lut_offset(cell[0].ix, cell[0].iy, 0.0f);
+            GdCorners c0 = gd_corners_load(cell[0], s.lut);
+            k.lo = gd_mix(c0.a, c0.b, cell[0].ux); k.hi = gd_mix(c0.c, c0.d, cell[0].ux); k.iy = cell[0].iy;
+        }
+        value = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(k.hi, y[1], k.lo * y[2]), 2.0f, -1.0f), amp[0], value);
+#pragma unroll
+        for (int i = 1; i < octaves; i++) value = __builtin_fmaf(gd_noise2_combine(cell[i], c[i]), amp[i], value);
+    } else {
+#pragma unroll
+        for (int i = 0; i < octaves; i++) value = __builtin_fmaf(gd_noise2_combine(cell[i], gd_corners_hash(cell[i])), amp[i], value);
+    }
+    s.sdf = value * gd_rcp(max_val);
+}
 GD void gb_curl_noise(GdPix& s, float frequency, float amplitude)                                       // :367-377
 {
     const float eps = 0.001f;

@@ -196,6 +196,31 @@ def test_domain_warp_across_lattice_rows(game, oracle, warp):
         assert np.array_equal(band, want[0, 13:224])
 
 
+@pytest.mark.parametrize("first", ["voronoi(40.0)", "voronoi(400.0)", "voronoi(knob)", "voronoi(time)", "voronoi(0.0)", "voronoi(3.0 + p.x)",
+                                   "fbm(40.0, octaves: 3)", "fbm(300.0, octaves: 2)", "fbm(knob, octaves: 8, persistence: 0.7, lacunarity: 1.7)",
+                                   "fbm(time, 1.0)", "fbm(2.0, knob)", "fbm(2.0 + sin(time), 4.0, 0.5, 2.0)", "fbm(0.000001, 6.0)"],
+                         ids=["voronoi-fine", "voronoi-leaves-table", "voronoi-uniform", "voronoi-time", "voronoi-zero", "voronoi-pixel-argument",
+                              "fbm-fine", "fbm-leaves-table", "fbm-uniform-8", "fbm-time", "fbm-uniform-octaves", "fbm-expression", "fbm-tiny"])
+def test_noise_generators_across_lattice_rows(game, oracle, first):
+    """voronoi and fbm that open a layer keep per-lane lattice state from row to row (the nine feature points' x terms;
+    octave 0's x-interpolated values) and take their y halves from the workgroup's row values: tall frames that cross
+    many lattice rows, scales that leave the tables, scales from uniforms / time / a per-frame expression, an octave count
+    from a uniform and a pixel-reading argument (plain forms), bands, both wordings."""
+    src = 'cinematic "n" { layer a { fn: %s | glow(1.5) | tint(1.0, 0.6, 0.3) } layer b { fn: %s | glow(0.7) } }' % (first, first)
+    cin = game.compile(src).cinematics[0]
+    w, h = 40, 1100
+    rows = cin.uniform_rows([0.0, 9.3], w, h, user={"knob": [5.0, 31.5]} if "knob" in first else None)
+    for sem in ("glsl", "wgsl"):
+        animate = "p.x" in first or "sin(" in first
+        r = cin.renderer(w, h, semantics=sem, animate=animate)
+        got = r.render(rows)
+        want = oracle.render_sequence(cin.blob, w, h, rows, False, semantics=sem, derived=cin.eval_derived(rows) if animate else None, animate=animate)
+        assert np.array_equal(got, want), (first, sem)
+        band = r.render_band(rows[1:], 7, 333)[0]
+        r.close()
+        assert np.array_equal(band, want[1, 7:340])
+
+
 def test_c2b_tutorial_noise(game, oracle):
     check(game, oracle, C2B_NOISE, 320, 180, [0.0, 3.7], user={"frost": [0.0, 0.6], "ember": [0.0, 0.9], "violet": [0.0, 0.3]})
 
