@@ -310,6 +310,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     std::string row_state;   // declarations that live across the rows of a lane, placed ahead of the row loop
     std::string row_prologue;   // what lane r of the workgroup stores for row r besides uv.y
     uint32_t row_floats = 4;     // uv.y and padding first
+    uint32_t row_regs = 0;       // registers a lane holds across its rows for the cached stages
     for (size_t li = 0; li < ir.layers.size(); ++li) {
         const IrLayer& L = ir.layers[li];
         if (!L.is_pipeline || L.end_state != State::Color) continue;
@@ -349,14 +350,17 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
             }
             // kind of cache, its y-prologue function, floats it takes in the workgroup's row values, index of the argument the
             // y half is scaled by
-            const char* kind = nullptr; const char* type = nullptr; uint32_t floats = 0; size_t yarg = 0;
+            const char* kind = nullptr; const char* type = nullptr; uint32_t floats = 0, regs = 0; size_t yarg = 0;
             if (!av.empty()) {
-                if (st.builtin == B_DOMAIN_WARP && av.size() == 2) { kind = "warp"; type = "GdWarpRows"; floats = 8; yarg = 1; }
-                else if (st.builtin == B_VORONOI && !shape.wgsl && av.size() == 1) { kind = "voronoi"; type = "GdVoronoiRows"; floats = 4; yarg = 0; }
+                if (st.builtin == B_DOMAIN_WARP && av.size() == 2) { kind = "warp"; type = "GdWarpRows"; floats = 8; regs = 6; yarg = 1; }
+                else if (st.builtin == B_VORONOI && !shape.wgsl && av.size() == 1) { kind = "voronoi"; type = "GdVoronoiRows"; floats = 4; regs = 19; yarg = 0; }
                 else if (st.builtin == B_FBM && av.size() == 4 && st.args[1].kind == ARG_LIT && octaves_of(st.args[1].lit) >= 1 &&
-                         octaves_of(st.args[1].lit) <= 8) { kind = "fbm"; type = "GdFbmRows"; floats = 4; yarg = 0; }
+                         octaves_of(st.args[1].lit) <= 8) { kind = "fbm"; type = "GdFbmRows"; floats = 4; regs = 3; yarg = 0; }
             }
+            // a cinematic of many layers keeps this state for the first few only: 48 registers and 44 row values at most
+            if (kind && (row_regs + regs > 48u || row_floats + floats > 48u)) kind = nullptr;
             if (kind) {
+                row_regs += regs;
                 const std::string cache = std::string(kind) + "_rows_" + std::to_string(li);
                 std::string scale = av[yarg];
                 if (scale == "s.time") scale = "U[" + std::to_string(shape.time_slot) + "]";          // ahead of the loop there is no `s` yet

@@ -221,6 +221,13 @@ def test_noise_generators_across_lattice_rows(game, oracle, first):
         assert np.array_equal(band, want[1, 7:340])
 
 
+def test_more_layers_than_row_state(game, oracle):
+    """Twelve layers that each open with voronoi: only the first two keep row state (a lane's registers are bounded), the
+    rest take the plain form, and the frame is the same."""
+    layers = "\n".join("  layer l%d { fn: voronoi(%d.0) | glow(1.0) | tint(0.1, 0.%d, 0.3) }" % (i, i + 2, i % 10) for i in range(12))
+    check(game, oracle, 'cinematic "many" {\n' + layers + "\n}", 48, 600, [0.3])
+
+
 def test_c2b_tutorial_noise(game, oracle):
     check(game, oracle, C2B_NOISE, 320, 180, [0.0, 3.7], user={"frost": [0.0, 0.6], "ember": [0.0, 0.9], "violet": [0.0, 0.3]})
 
