@@ -214,6 +214,10 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     // load and store instruction of a wave still covers one contiguous KiB) and issue all previous-frame loads
     // before any arithmetic: more bytes in flight per wave for the cinematics the memory system bounds.
     const uint32_t nvec = shape.pixels_per_lane >= 4 ? shape.pixels_per_lane / 4u : 0u;
+    // how the previous frame is read: every byte once, so for frames that cannot stay in cache from one launch to the next
+    // the load says so (non-temporal: it does not displace what the cache holds)
+    const std::string ld4 = shape.stream_prev ? "__builtin_nontemporal_load((const gd_u32x4*)" : "*((const gd_u32x4*)";
+    const std::string ld1 = shape.stream_prev ? "__builtin_nontemporal_load((const gd_u32*)" : "*((const gd_u32*)";
     const std::string ppl = std::to_string(shape.pixels_per_lane);
     if (nvec > 1) k += "    const gd_u32 x0 = blockIdx.x * " + std::to_string(shape.wg * shape.pixels_per_lane) + "u + threadIdx.x * 4u;\n";
     else k += "    const gd_u32 x0 = (blockIdx.x * " + wg + "u + threadIdx.x) * " + ppl + "u;\n";
@@ -261,7 +265,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
             k += "    gd_u32x4 pv[" + nv + "];\n";
             k += "#pragma unroll\n    for (gd_u32 v = 0; v < " + nv + "u; ++v) {\n"
                  "        pv[v] = gd_u32x4{0u, 0u, 0u, 0u};\n"
-                 "        if (P.prev && x0 + v * " + std::to_string(shape.wg * 4u) + "u < P.w) pv[v] = *(const gd_u32x4*)(P.prev + (unsigned long long)ty * P.w + x0 + v * " + std::to_string(shape.wg * 4u) + "u);\n"
+                 "        if (P.prev && x0 + v * " + std::to_string(shape.wg * 4u) + "u < P.w) pv[v] = " + ld4 + "(P.prev + (unsigned long long)ty * P.w + x0 + v * " + std::to_string(shape.wg * 4u) + "u));\n"
                  "    }\n";
         }
         k += "#pragma unroll\n    for (gd_u32 v = 0; v < " + nv + "u; ++v) {\n";
@@ -275,7 +279,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
         // the host picks this shape only when the width is a multiple of 4: rows stay 16-byte aligned
         if (ir.uses_memory)
             k += "    gd_u32x4 pv = {0u, 0u, 0u, 0u};\n"
-                 "    if (P.prev) pv = *(const gd_u32x4*)(P.prev + (unsigned long long)ty * P.w + x0);\n";
+                 "    if (P.prev) pv = " + ld4 + "(P.prev + (unsigned long long)ty * P.w + x0));\n";
         k += "    gd_u32x4 q;\n";
         k += "#pragma unroll\n    for (gd_u32 kx = 0; kx < 4u; ++kx) {\n    const gd_u32 x = x0 + kx;\n";
         k += "    {\n";
@@ -283,7 +287,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     } else {
         k += "    {\n    const gd_u32 x = x0;\n    {\n";
         if (ir.uses_memory)
-            k += "    const gd_u32 prev = P.prev ? P.prev[(unsigned long long)ty * P.w + x] : 0u;\n";
+            k += "    const gd_u32 prev = P.prev ? " + ld1 + "(P.prev + (unsigned long long)ty * P.w + x)) : 0u;\n";
     }
     k += "    const float vx = ((float)x + 0.5f) * P.inv_w;\n";
     const bool warp = shape.project && ir.project.present && (ir.project.mode == ProjectMode::Dome || ir.project.mode == ProjectMode::Led);
