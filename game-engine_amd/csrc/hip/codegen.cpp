@@ -219,20 +219,15 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     const std::string ld4 = shape.stream_prev ? "__builtin_nontemporal_load((const gd_u32x4*)" : "*((const gd_u32x4*)";
     const std::string ld1 = shape.stream_prev ? "__builtin_nontemporal_load((const gd_u32*)" : "*((const gd_u32*)";
     const std::string ppl = std::to_string(shape.pixels_per_lane);
-    // A row is cut into gridDim.x strips of equal width (strip_lanes lanes each; the last lanes of a workgroup idle)
-    // rather than into full workgroups plus a remainder: workgroups go to the eight XCDs round robin, so with 8, 4 or 2
-    // strips per row one XCD would own every remainder strip and sit idle while the others finish.
-    const uint32_t strip = (shape.strip_lanes && shape.strip_lanes < shape.wg && nvec <= 1) ? shape.strip_lanes : shape.wg;
     if (nvec > 1) k += "    const gd_u32 x0 = blockIdx.x * " + std::to_string(shape.wg * shape.pixels_per_lane) + "u + threadIdx.x * 4u;\n";
-    else k += "    const gd_u32 x0 = (blockIdx.x * " + std::to_string(strip) + "u + threadIdx.x) * " + ppl + "u;\n";
-    const std::string outside = strip < shape.wg ? "threadIdx.x >= " + std::to_string(strip) + "u || x0 >= P.w" : "x0 >= P.w";
+    else k += "    const gd_u32 x0 = (blockIdx.x * " + wg + "u + threadIdx.x) * " + ppl + "u;\n";
     // Several rows per lane: what a row needs from y alone (uv.y, and the y halves of a leading domain_warp's lattice
     // samples) is the same for every lane of the workgroup, so lane r of the workgroup works it out for row r once, into
     // shared memory, and the row loop reads it from there. The early return of lanes beyond the right edge then comes
     // after the barrier.
     const bool project_warp = shape.project && ir.project.present && (ir.project.mode == ProjectMode::Dome || ir.project.mode == ProjectMode::Led);
     const bool row_lds = shape.row_shared && shape.rows_per_lane > 1 && !project_warp && shape.wg >= shape.rows_per_lane;
-    if (!row_lds) k += "    if (" + outside + ") return;\n";
+    if (!row_lds) k += "    if (x0 >= P.w) return;\n";
     // The uniform row is read through the constant address space: nothing writes it while the kernel runs, so its
     // loads are scalar and invariant. Every slot the pipeline reads is loaded here, ahead of the row loop, so that
     // whatever is computed from uniforms and the column alone leaves the loop with them.
@@ -431,7 +426,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
         shared += "        const float uvy = vy * 2.0f - 1.0f;\n";
         shared += "        gd_rowv[threadIdx.x * GD_ROWV] = uvy;\n";
         shared += row_prologue;
-        shared += "    }\n    __syncthreads();\n    if (" + outside + ") return;\n";
+        shared += "    }\n    __syncthreads();\n    if (x0 >= P.w) return;\n";
     }
     k.insert(uniform_loads_at, loads + shared + row_state);
     return k;

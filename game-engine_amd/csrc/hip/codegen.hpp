@@ -16,7 +16,6 @@ struct KernelShape {
     bool lens_post = false;         // run the lens post chain on the composited colour
     bool project = false;           // apply the cinematic's projection block (Ir::project) to v_uv
     uint32_t wg = 256;              // threads per workgroup (a multiple of 64)
-    uint32_t strip_lanes = 0;       // lanes of a workgroup that own pixels (0 = all): the row divided evenly over its workgroups
     bool stream_prev = false;       // the previous frame is read with a non-temporal hint (frames too large to stay in cache)
     bool row_shared = true;         // with several rows per lane: per-row values worked out once per workgroup, in shared memory
 };

@@ -256,14 +256,6 @@ KernelShape shape_for(const Ir& ir, uint32_t width, uint32_t height, uint32_t fl
         int v = atoi(e);
         if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) s.wg = (uint32_t)v;
     }
-    if (!ir.uses_memory) {   // equal strips: the lanes a row needs, divided over the workgroups it takes anyway. Stateless cinematics
-                             // only: c3 +2 to +7 % at 4K (4 strips of 960 pixels instead of 3 x 1024 + 768); the 8K feedback kernel
-                             // loses 3 % with 8 x 960 against 7 x 1024 + 512 (and 8 % when the strips rotate over the XCDs)
-        const uint32_t lanes = (width + s.pixels_per_lane - 1u) / s.pixels_per_lane;
-        const uint32_t groups = (lanes + s.wg - 1u) / s.wg;
-        s.strip_lanes = groups ? (lanes + groups - 1u) / groups : 0u;
-        if (const char* e = getenv("GAME_HIP_STRIPS")) if (atoi(e) == 0) s.strip_lanes = 0;   // tuning hook
-    }
     uint32_t row = BU_COUNT + (uint32_t)ir.uniforms.size();
     s.time_slot = row;
     s.aspect_slot = row + 1;

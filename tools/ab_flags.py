@@ -16,9 +16,9 @@ rs = []
 ref = None
 for v in variants:
     # a variant is hiprtc flags, optionally prefixed by shape settings: "PPL=n,RPL=m;flags" (pixels / rows per lane)
-    head, _, fl = v.partition(";") if v.startswith(("PPL=", "RPL=", "ROWLDS=", "WG=", "STRIPS=", "NTLOAD=")) else ("", "", v)
+    head, _, fl = v.partition(";") if v.startswith(("PPL=", "RPL=", "ROWLDS=", "WG=")) else ("", "", v)
     os.environ["GAME_HIP_FLAGS"] = fl
-    for name in ("PPL", "RPL", "ROWLDS", "WG", "STRIPS", "NTLOAD"):
+    for name in ("PPL", "RPL", "ROWLDS", "WG"):
         os.environ.pop("GAME_HIP_" + name, None)
     for item in filter(None, head.split(",")):
         name, _, val = item.partition("=")
