@@ -339,39 +339,33 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
             // the pixel, and not under a projection, which moves uv.x from row to row.
             bool reads_pixel = false;
             for (uint32_t ai = 0; ai < 4; ++ai) reads_pixel = reads_pixel || (shape.animate && st.args[ai].pixel >= 0);
-            // split "gb_name(s, a, b, ...);" into its name and arguments as written
-            std::vector<std::string> av;
-            const size_t open = text.find("(s, ");
-            if (si == 0 && row_lds && shape.pixels_per_lane == 1 && !reads_pixel && open != std::string::npos && text.size() > open + 6 &&
-                text.compare(text.size() - 2, 2, ");") == 0) {
-                const std::string inner = text.substr(open + 4, text.size() - 2 - (open + 4));
-                for (size_t b = 0; b <= inner.size();) {
-                    const size_t e = inner.find(", ", b);
-                    av.push_back(inner.substr(b, e == std::string::npos ? std::string::npos : e - b));
-                    if (e == std::string::npos) break;
-                    b = e + 2;
+            // kind of cache, floats it takes in the workgroup's row values, registers it holds, the argument its y half is
+            // scaled by, and the call with the cache and the row values appended
+            const char* kind = nullptr; const char* type = nullptr; uint32_t floats = 0, regs = 0; int yarg = 0;
+            auto A = [&](int i) { return arg_expr(st.args[i], shape, ir); };
+            std::string head;
+            if (si == 0 && row_lds && shape.pixels_per_lane == 1 && !reads_pixel) {
+                if (st.builtin == B_DOMAIN_WARP) {
+                    kind = "warp"; type = "GdWarpRows"; floats = 8; regs = 6; yarg = 1;
+                    head = "gb_domain_warp_rows(s, " + A(0) + ", " + A(1);
+                } else if (st.builtin == B_VORONOI && !shape.wgsl) {
+                    kind = "voronoi"; type = "GdVoronoiRows"; floats = 4; regs = 19; yarg = 0;
+                    head = "gb_voronoi_rows(s, " + A(0);
+                } else if (st.builtin == B_FBM && st.args[1].kind == ARG_LIT && octaves_of(st.args[1].lit) >= 1 && octaves_of(st.args[1].lit) <= 8) {
+                    kind = "fbm"; type = "GdFbmRows"; floats = 4; regs = 3; yarg = 0;
+                    head = "gb_fbm_rows(s, " + A(0) + ", " + std::to_string(octaves_of(st.args[1].lit)) + ", " + A(2) + ", " + A(3);
                 }
-            }
-            // kind of cache, its y-prologue function, floats it takes in the workgroup's row values, index of the argument the
-            // y half is scaled by
-            const char* kind = nullptr; const char* type = nullptr; uint32_t floats = 0, regs = 0; size_t yarg = 0;
-            if (!av.empty()) {
-                if (st.builtin == B_DOMAIN_WARP && av.size() == 2) { kind = "warp"; type = "GdWarpRows"; floats = 8; regs = 6; yarg = 1; }
-                else if (st.builtin == B_VORONOI && !shape.wgsl && av.size() == 1) { kind = "voronoi"; type = "GdVoronoiRows"; floats = 4; regs = 19; yarg = 0; }
-                else if (st.builtin == B_FBM && av.size() == 4 && st.args[1].kind == ARG_LIT && octaves_of(st.args[1].lit) >= 1 &&
-                         octaves_of(st.args[1].lit) <= 8) { kind = "fbm"; type = "GdFbmRows"; floats = 4; regs = 3; yarg = 0; }
             }
             // a cinematic of many layers keeps this state for the first few only: 48 registers and 44 row values at most
             if (kind && (row_regs + regs > 48u || row_floats + floats > 48u)) kind = nullptr;
             if (kind) {
                 row_regs += regs;
                 const std::string cache = std::string(kind) + "_rows_" + std::to_string(li);
-                std::string scale = av[yarg];
+                std::string scale = A(yarg);
                 if (scale == "s.time") scale = "U[" + std::to_string(shape.time_slot) + "]";          // ahead of the loop there is no `s` yet
                 const std::string at = std::to_string(row_floats);
                 const std::string rowp = "&gd_rowv[ry * GD_ROWV + " + at + "]";
-                text = "gb_" + (st.builtin == B_DOMAIN_WARP ? std::string("domain_warp") : std::string(kind)) + "_rows" + text.substr(open, text.size() - 2 - open) + ", " + cache + ", " +
-                       (st.builtin == B_DOMAIN_WARP ? "*(const GdWarpY*)" + rowp : rowp) + ");";
+                text = head + ", " + cache + ", " + (st.builtin == B_DOMAIN_WARP ? "*(const GdWarpY*)" + rowp : rowp) + ");";
                 row_state += "    " + std::string(type) + " " + cache + "; gd_" + kind + "_rows_reset(" + cache + ");\n";
                 row_prologue += "        gd_" + std::string(kind) + "_rows_y(uvy, " + scale + ", &gd_rowv[threadIdx.x * GD_ROWV + " + at + "]);\n";
                 row_floats += floats;
