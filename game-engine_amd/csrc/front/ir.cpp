@@ -944,7 +944,7 @@ bool ir_deserialize(const uint8_t* data, size_t len, Ir& ir, std::string& why)
         if (!finite32(l.decay)) return fail("a memory decay is not finite");
         l.end_state = (State)end_state;
         l.decay_text = fmt_f64_display((double)l.decay);
-        any_memory = any_memory || (l.is_pipeline && l.has_memory);
+        any_memory = any_memory || l.has_memory;     // as the lowering sets it: any layer with a memory clause
     }
     if (any_memory != ir.uses_memory) return fail("uses_memory disagrees with the layers");
     struct Packed { uint32_t v[4]; };

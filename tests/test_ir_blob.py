@@ -23,6 +23,8 @@ project dome (fisheye: 150) { source: e }'''
 
 def sources(game):
     out = [C1_HELLO, C2_FBM, C2B_NOISE, C3_SHOWCASE, C4_TRAILS, C5_GRAVITY, EXPRESSIVE] + list(GALLERY.values())
+    # a memory clause on a layer that only declares parameters still marks the cinematic as using memory
+    out.append('cinematic "m" { layer cfg memory: 0.9 { speed: 1.0 } layer a { fn: circle(0.2) | glow(2.0) } }')
     for seed in range(40):
         out.append(make_cinematic(game, random.Random(1000 + seed), expressions=seed % 2 == 1)[0])
     return out
