@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """A/B of kernel build variants on the GPU, interleaved rounds in one process.
-usage: tools/ab_flags.py <config> "<flags A>" "<flags B>" ...   ("" = default build)"""
+usage: tools/ab_flags.py <config> "<flags A>" "<flags B>" ...   ("" = default build)
+All variants live in one process and share the GPU; memory cinematics run with a 25-slot ring here. Differences of a
+few percent have pointed the wrong way with this tool: confirm them with `bench.py --config <c>` under the same
+GAME_HIP_* settings, alternating on one box."""
 import os, sys, statistics
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
@@ -8,6 +11,7 @@ import conftest as T
 g = T.load_product()
 key = sys.argv[1]
 variants = sys.argv[2:] or [""]
+HOOKS = ("PPL=", "RPL=", "ROWLDS=", "WG=", "NTLOAD=")     # GAME_HIP_<name> shape hooks of the runtime
 cfg = g.workloads.CONFIGS[key]
 cin = g.compile(cfg["src"]).cinematics[0]
 w, h, batch = cfg["w"], cfg["h"], 25
@@ -16,9 +20,9 @@ rs = []
 ref = None
 for v in variants:
     # a variant is hiprtc flags, optionally prefixed by shape settings: "PPL=n,RPL=m;flags" (pixels / rows per lane)
-    head, _, fl = v.partition(";") if v.startswith(("PPL=", "RPL=", "ROWLDS=", "WG=")) else ("", "", v)
+    head, _, fl = v.partition(";") if v.startswith(HOOKS) else ("", "", v)
     os.environ["GAME_HIP_FLAGS"] = fl
-    for name in ("PPL", "RPL", "ROWLDS", "WG"):
+    for name in (h[:-1] for h in HOOKS):
         os.environ.pop("GAME_HIP_" + name, None)
     for item in filter(None, head.split(",")):
         name, _, val = item.partition("=")
