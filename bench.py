@@ -309,6 +309,26 @@ def time_frames(args, game, torch, rank, world, local, key, steps, warmup, extra
     return out
 
 
+def sync_with_heartbeat(r, label, every=20.0):
+    """r.sync() for work that takes minutes: a line on stderr every `every` seconds while the GPU works, so that
+    whoever watches the run sees it is alive (the wait itself is the library's stream synchronisation)."""
+    import threading
+    done = threading.Event()
+
+    def beat():
+        t0 = time.time()
+        while not done.wait(every):
+            print(f"[bench] {label}: GPU busy, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+
+    th = threading.Thread(target=beat, daemon=True)
+    th.start()
+    try:
+        r.sync()
+    finally:
+        done.set()
+        th.join()
+
+
 def time_particles(args, game, torch, rank, world, local, n, steps, warmup, extras, fast=False):
     cin = game.compile(game.workloads.C5_GRAVITY).cinematics[0]
     first, count = game.distributed.particle_range(n, rank, world)
@@ -333,7 +353,7 @@ def time_particles(args, game, torch, rank, world, local, n, steps, warmup, extr
         step()
     if gather:
         gather.finish()
-    r.sync()
+    sync_with_heartbeat(r, f"gravity step, {n} particles")
     barrier(torch, world)
     dt = max_over_ranks(torch, world, time.perf_counter() - t0)
     if args.events:
@@ -347,7 +367,7 @@ def time_particles(args, game, torch, rank, world, local, n, steps, warmup, extr
                       "parallelism": f"index{world}"},
            "timed_region_s": round(dt, 4)}
     if rank == 0 and args.events and launches:
-        sec = kernel_ms / launches / 1e3
+        sec = kernel_ms / steps / 1e3          # device time of one step of this rank's range (one launch per 2^20 particles)
         flops = 20.0 * count * (n - 1) + 12.0 * count
         pmc = measured_counters("c5", n, r.kernel_hash) if world == 1 and not fast else None
         roof = valu_roofline(pmc, sec, flops)
@@ -357,7 +377,8 @@ def time_particles(args, game, torch, rank, world, local, n, steps, warmup, extr
             roof["valu_issue_frac"] = roof["frac"]
         roof.update({"achieved": roof["algorithmic_tflops"], "frac": roof["algorithmic_over_peak"],
                      "frac_definition": "20 flop per pair + 12 per particle, over the FP32 vector peak",
-                     "kernel": "game_gravity", "kernel_hash": r.kernel_hash, "avg_launch_ms": round(sec * 1e3, 4), "flops_per_pair": 20})
+                     "kernel": "game_gravity", "kernel_hash": r.kernel_hash, "avg_step_ms": round(sec * 1e3, 4),
+                     "launches_per_step": launches // steps, "flops_per_pair": 20})
         roof.pop("note", None)
         out["roofline"] = roof
     if rank == 0 and world == 1 and extras and not args.no_cpu:

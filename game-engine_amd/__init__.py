@@ -580,7 +580,7 @@ class Renderer:
 
 EVAL_OPS = {"fract": 0, "sin": 1, "cos": 2, "atan2": 3, "hash2": 4, "noise2": 5, "simplex2d": 6, "voronoi2d": 7,
             "exp2": 8, "log2": 9, "pow": 10, "max": 11, "min": 12, "fbm6": 13, "sqrt": 14, "div": 15,
-            "smoothstep_glow": 16, "mod": 17, "unorm8": 18, "noise2_lut": 19, "fbm6_lut": 20, "voronoi2d_lut": 21, "simplex2d_lut": 22, "pack_unorm8": 23}
+            "smoothstep_glow": 16, "mod": 17, "unorm8": 18, "noise2_lut": 19, "fbm6_lut": 20, "voronoi2d_lut": 21, "simplex2d_lut": 22, "pack_unorm8": 23, "rsqrt": 24}
 
 
 def device_eval(op, a, b=None):

@@ -26,5 +26,7 @@ int set_error(int code, const std::string& msg);
 int lut_for_current_device(int kind, const float** table);
 // Frees every table built so far (game_hip_shutdown).
 int release_device_tables();
+// Render contexts alive right now (created and not yet destroyed): they hold pointers into those tables.
+int live_context_count();
 int error_code_of(const CompileError& e);
 }  // namespace game

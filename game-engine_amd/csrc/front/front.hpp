@@ -233,7 +233,7 @@ enum LawOp : uint32_t { LAW_NUM = 0, LAW_DIST, LAW_TIME, LAW_ADD, LAW_SUB, LAW_M
                         LAW_NEG, LAW_CALL1, LAW_CALL2, LAW_CALL3, LAW_UNIFORM, LAW_PX, LAW_PY, LAW_UVX, LAW_UVY };
 enum LawFn : uint32_t { LF_SIN = 0, LF_COS, LF_TAN, LF_ABS, LF_SQRT, LF_EXP, LF_LOG, LF_FLOOR, LF_CEIL, LF_FRACT, LF_SIGN,
                         LF_MIN, LF_MAX, LF_POW, LF_STEP, LF_CLAMP, LF_MIX, LF_SMOOTHSTEP, LF_EXP2, LF_LOG2,
-                        LF_ROUND, LF_MOD, LF_ATAN2, LF_LENGTH2, LF_COUNT };
+                        LF_ROUND, LF_MOD, LF_ATAN2, LF_LENGTH2, LF_SELECT, LF_COUNT };
 struct IrLawOp { uint32_t op = LAW_NUM; float val = 0.0f; uint32_t fn = 0; };
 struct IrGravity {
     bool present = false;

@@ -133,43 +133,75 @@ std::string expr_source_text(const Expr& e)
         for (size_t i = 0; i < e.args.size(); ++i) t += (i ? ", " : "") + expr_source_text(e.args[i].value);
         return t + ")";
     }
+    case Expr::Ternary:
+        return "(" + expr_source_text(e.kids[0]) + " ? " + expr_source_text(e.kids[1]) + " : " + expr_source_text(e.kids[2]) + ")";
     default: return "?";
     }
 }
 
-// A lowered (sub)expression: one postfix program for a scalar, two (x and y component) for a vec2. Vector values
-// exist only while lowering: `p`, `uv`, two-element arrays and the operators / functions over them (expr.rs:50-144
-// words them as WGSL vec2f arithmetic) are expanded component by component, so what reaches the IR is always a
-// scalar program. length(v) becomes the two-argument function length2(x, y); dot, distance and normalize expand to
-// their defining sums, differences and quotients.
+// A lowered (sub)expression: one postfix program per component - one for a scalar, two for a vec2, three for a
+// colour. Vector values exist only while lowering: `p`, `uv`, the nineteen named colours (expr.rs:13-36), two- and
+// three-element arrays and the operators / functions over them (expr.rs:50-144 words them as WGSL vec2f / vec3f
+// arithmetic) are expanded component by component, so what reaches the IR is always a scalar program. length(v)
+// of a vec2 becomes the two-argument function length2(x, y); dot, distance and normalize expand to their defining
+// sums, differences and quotients.
 struct LoweredValue {
-    bool vec = false;
-    std::vector<IrLawOp> x, y;
-    const std::vector<IrLawOp>& comp(int c) const { return vec && c == 1 ? y : x; }
+    int dim = 1;
+    std::vector<IrLawOp> c[3];
+    bool vec() const { return dim > 1; }
+    const std::vector<IrLawOp>& comp(int k) const { return dim > 1 ? c[k] : c[0]; }   // a scalar is broadcast
 };
 
 void append(std::vector<IrLawOp>& dst, const std::vector<IrLawOp>& src) { dst.insert(dst.end(), src.begin(), src.end()); }
 IrLawOp law_op(uint32_t op, float v = 0.0f, uint32_t fn = 0) { IrLawOp o; o.op = op; o.val = v; o.fn = fn; return o; }
 
+// The named colours of expr.rs:13-36 (`vec3f(r, g, b)`).
+const float* named_color(const std::string& n)
+{
+    static const struct { const char* n; float v[3]; } tab[] = {
+        {"black", {0.0f, 0.0f, 0.0f}}, {"white", {1.0f, 1.0f, 1.0f}}, {"red", {1.0f, 0.0f, 0.0f}}, {"green", {0.0f, 1.0f, 0.0f}},
+        {"blue", {0.0f, 0.0f, 1.0f}}, {"gold", {0.831f, 0.686f, 0.216f}}, {"midnight", {0.039f, 0.039f, 0.118f}},
+        {"obsidian", {0.071f, 0.059f, 0.082f}}, {"ember", {0.898f, 0.318f, 0.129f}}, {"cyan", {0.0f, 1.0f, 1.0f}},
+        {"ivory", {1.0f, 1.0f, 0.941f}}, {"frost", {0.686f, 0.878f, 0.953f}}, {"orange", {1.0f, 0.647f, 0.0f}},
+        {"deep_blue", {0.0f, 0.098f, 0.392f}}, {"ash", {0.467f, 0.467f, 0.467f}}, {"charcoal", {0.212f, 0.212f, 0.212f}},
+        {"plasma", {0.580f, 0.0f, 0.827f}}, {"violet", {0.541f, 0.169f, 0.886f}}, {"magenta", {1.0f, 0.0f, 1.0f}}};
+    for (auto& k : tab) if (n == k.n) return k.v;
+    return nullptr;
+}
+
+// Two operand shapes combine when they are equal or one of them is a scalar; the result has the larger one.
+bool combine_dims(int a, int b, int& out)
+{
+    if (a != b && a != 1 && b != 1) return false;
+    out = a > b ? a : b;
+    return true;
+}
+
 bool lower_value(const Expr& e, const std::map<std::string, uint32_t>& uslot, bool allow_pixel, LoweredValue& out)
 {
     out = LoweredValue{};
+    auto rec = [&](const Expr& k, LoweredValue& v) { return lower_value(k, uslot, allow_pixel, v); };
     switch (e.kind) {
-    case Expr::Number: out.x.push_back(law_op(LAW_NUM, (float)e.num)); return true;
+    case Expr::Number: out.c[0].push_back(law_op(LAW_NUM, (float)e.num)); return true;
     case Expr::Dur:
-        out.x.push_back(law_op(LAW_NUM, (float)(e.dur.kind == DurKind::Seconds ? e.dur.v : e.dur.kind == DurKind::Millis ? e.dur.v / 1000.0 : (double)e.dur.bars * 2.0)));
+        out.c[0].push_back(law_op(LAW_NUM, (float)(e.dur.kind == DurKind::Seconds ? e.dur.v : e.dur.kind == DurKind::Millis ? e.dur.v / 1000.0 : (double)e.dur.bars * 2.0)));
         return true;
     case Expr::Ident: {
-        if (e.s == "time") { out.x.push_back(law_op(LAW_UNIFORM, 0.0f, BU_TIME)); return true; }
+        if (e.s == "time") { out.c[0].push_back(law_op(LAW_UNIFORM, 0.0f, BU_TIME)); return true; }
+        if (const float* col = named_color(e.s)) {     // expr.rs:60-67: a colour name first, then a constant, then the name itself
+            out.dim = 3;
+            for (int k = 0; k < 3; ++k) out.c[k].push_back(law_op(LAW_NUM, col[k]));
+            return true;
+        }
         static const struct { const char* n; float v; } consts[] = {   // expr.rs:39-47
             {"pi", 3.14159265358979f}, {"tau", 6.28318530717959f}, {"e", 2.71828182845905f}, {"phi", 1.61803398874989f}};
-        for (auto& k : consts) if (e.s == k.n) { out.x.push_back(law_op(LAW_NUM, k.v)); return true; }
+        for (auto& k : consts) if (e.s == k.n) { out.c[0].push_back(law_op(LAW_NUM, k.v)); return true; }
         auto it = uslot.find(e.s);
-        if (it != uslot.end()) { out.x.push_back(law_op(LAW_UNIFORM, 0.0f, BU_COUNT + it->second)); return true; }
+        if (it != uslot.end()) { out.c[0].push_back(law_op(LAW_UNIFORM, 0.0f, BU_COUNT + it->second)); return true; }
         if (allow_pixel && (e.s == "p" || e.s == "uv")) {   // the position / the normalised pixel coordinate as vec2
-            out.vec = true;
-            out.x.push_back(law_op(e.s == "p" ? LAW_PX : LAW_UVX));
-            out.y.push_back(law_op(e.s == "p" ? LAW_PY : LAW_UVY));
+            out.dim = 2;
+            out.c[0].push_back(law_op(e.s == "p" ? LAW_PX : LAW_UVX));
+            out.c[1].push_back(law_op(e.s == "p" ? LAW_PY : LAW_UVY));
             return true;
         }
         return false;
@@ -178,75 +210,91 @@ bool lower_value(const Expr& e, const std::map<std::string, uint32_t>& uslot, bo
         static const struct { const char* o; const char* f; uint32_t slot; } dotted[] = {
             {"audio", "bass", BU_AUDIO_BASS}, {"audio", "mid", BU_AUDIO_MID}, {"audio", "treble", BU_AUDIO_TREBLE},
             {"audio", "energy", BU_AUDIO_ENERGY}, {"audio", "beat", BU_AUDIO_BEAT}, {"mouse", "x", BU_MOUSE_X}, {"mouse", "y", BU_MOUSE_Y}};
-        for (auto& d : dotted) if (e.s == d.o && e.field == d.f) { out.x.push_back(law_op(LAW_UNIFORM, 0.0f, d.slot)); return true; }
+        for (auto& d : dotted) if (e.s == d.o && e.field == d.f) { out.c[0].push_back(law_op(LAW_UNIFORM, 0.0f, d.slot)); return true; }
         if (allow_pixel && (e.s == "p" || e.s == "uv") && (e.field == "x" || e.field == "y")) {
-            out.x.push_back(law_op(e.s == "p" ? (e.field == "x" ? LAW_PX : LAW_PY) : (e.field == "x" ? LAW_UVX : LAW_UVY)));
+            out.c[0].push_back(law_op(e.s == "p" ? (e.field == "x" ? LAW_PX : LAW_PY) : (e.field == "x" ? LAW_UVX : LAW_UVY)));
             return true;
         }
         return false;
     }
-    case Expr::Array: {   // [a, b] -> vec2f(a, b) (expr.rs:70-81); longer arrays have no scalar use here
-        if (e.kids.size() != 2) return false;
-        LoweredValue a, b;
-        if (!lower_value(e.kids[0], uslot, allow_pixel, a) || !lower_value(e.kids[1], uslot, allow_pixel, b) || a.vec || b.vec) return false;
-        out.vec = true; out.x = a.x; out.y = b.x;
+    case Expr::Array: {   // [a, b] -> vec2f(a, b), [a, b, c] -> vec3f(a, b, c) (expr.rs:70-81); longer arrays have no use here
+        if (e.kids.size() != 2 && e.kids.size() != 3) return false;
+        out.dim = (int)e.kids.size();
+        for (int k = 0; k < out.dim; ++k) {
+            LoweredValue a;
+            if (!rec(e.kids[(size_t)k], a) || a.vec()) return false;
+            out.c[k] = a.c[0];
+        }
         return true;
     }
-    case Expr::Paren: return lower_value(e.kids[0], uslot, allow_pixel, out);
+    case Expr::Paren: return rec(e.kids[0], out);
     case Expr::Neg: {
-        if (!lower_value(e.kids[0], uslot, allow_pixel, out)) return false;
-        out.x.push_back(law_op(LAW_NEG));
-        if (out.vec) out.y.push_back(law_op(LAW_NEG));
+        if (!rec(e.kids[0], out)) return false;
+        for (int k = 0; k < out.dim; ++k) out.c[k].push_back(law_op(LAW_NEG));
         return true;
     }
     case Expr::Bin: {
         LoweredValue l, r;
-        if (!lower_value(e.kids[0], uslot, allow_pixel, l) || !lower_value(e.kids[1], uslot, allow_pixel, r)) return false;
+        if (!rec(e.kids[0], l) || !rec(e.kids[1], r)) return false;
         static const uint32_t ops[] = {LAW_ADD, LAW_SUB, LAW_MUL, LAW_DIV, LAW_POW, LAW_GT, LAW_LT};
         const uint32_t op = ops[(int)e.op];
-        out.vec = l.vec || r.vec;
-        if (out.vec && (op == LAW_GT || op == LAW_LT)) return false;   // a vec2<bool> has no scalar meaning as an argument
-        for (int c = 0; c < (out.vec ? 2 : 1); ++c) {                  // a scalar operand is broadcast
-            std::vector<IrLawOp>& dst = c ? out.y : out.x;
-            append(dst, l.comp(c)); append(dst, r.comp(c)); dst.push_back(law_op(op));
+        if (!combine_dims(l.dim, r.dim, out.dim)) return false;
+        if (out.vec() && (op == LAW_GT || op == LAW_LT)) return false;   // a vector of bools has no scalar meaning as an argument
+        for (int k = 0; k < out.dim; ++k) {                              // a scalar operand is broadcast
+            append(out.c[k], l.comp(k)); append(out.c[k], r.comp(k)); out.c[k].push_back(law_op(op));
+        }
+        return true;
+    }
+    case Expr::Ternary: {
+        // expr.rs:132-142 words `c ? t : f` as select(f, t, c). The condition is the 0 / 1 a comparison leaves (or any
+        // scalar: non-zero and not NaN counts as true, the JavaScript wording's truthiness); both branches are
+        // evaluated, as select does.
+        LoweredValue cnd, t, f;
+        if (!rec(e.kids[0], cnd) || cnd.vec() || !rec(e.kids[1], t) || !rec(e.kids[2], f)) return false;
+        if (!combine_dims(t.dim, f.dim, out.dim)) return false;
+        for (int k = 0; k < out.dim; ++k) {
+            append(out.c[k], cnd.c[0]); append(out.c[k], t.comp(k)); append(out.c[k], f.comp(k));
+            out.c[k].push_back(law_op(LAW_CALL3, 0.0f, LF_SELECT));
         }
         return true;
     }
     case Expr::Call: {
         std::vector<LoweredValue> args(e.args.size());
-        bool any_vec = false;
+        int dim = 1;
         for (size_t i = 0; i < e.args.size(); ++i) {
-            if (!lower_value(e.args[i].value, uslot, allow_pixel, args[i])) return false;
-            any_vec = any_vec || args[i].vec;
+            if (!rec(e.args[i].value, args[i])) return false;
+            if (!combine_dims(dim, args[i].dim, dim)) return false;
         }
-        auto sub = [&](const LoweredValue& a, const LoweredValue& b, int c, std::vector<IrLawOp>& dst) {
-            append(dst, a.comp(c)); append(dst, b.comp(c)); dst.push_back(law_op(LAW_SUB));
+        const bool any_vec = dim > 1;
+        auto sub = [&](const LoweredValue& a, const LoweredValue& b, int k, std::vector<IrLawOp>& dst) {
+            append(dst, a.comp(k)); append(dst, b.comp(k)); dst.push_back(law_op(LAW_SUB));
         };
         if (e.s == "length" && args.size() == 1) {
-            if (!args[0].vec) { out.x = args[0].x; out.x.push_back(law_op(LAW_CALL1, 0.0f, LF_ABS)); return true; }
-            append(out.x, args[0].x); append(out.x, args[0].y); out.x.push_back(law_op(LAW_CALL2, 0.0f, LF_LENGTH2));
+            if (dim == 3) return false;
+            if (!any_vec) { out.c[0] = args[0].c[0]; out.c[0].push_back(law_op(LAW_CALL1, 0.0f, LF_ABS)); return true; }
+            append(out.c[0], args[0].c[0]); append(out.c[0], args[0].c[1]); out.c[0].push_back(law_op(LAW_CALL2, 0.0f, LF_LENGTH2));
             return true;
         }
         if (e.s == "distance" && args.size() == 2) {
-            if (!any_vec) { sub(args[0], args[1], 0, out.x); out.x.push_back(law_op(LAW_CALL1, 0.0f, LF_ABS)); return true; }
-            sub(args[0], args[1], 0, out.x); sub(args[0], args[1], 1, out.x); out.x.push_back(law_op(LAW_CALL2, 0.0f, LF_LENGTH2));
+            if (dim == 3) return false;
+            if (!any_vec) { sub(args[0], args[1], 0, out.c[0]); out.c[0].push_back(law_op(LAW_CALL1, 0.0f, LF_ABS)); return true; }
+            sub(args[0], args[1], 0, out.c[0]); sub(args[0], args[1], 1, out.c[0]); out.c[0].push_back(law_op(LAW_CALL2, 0.0f, LF_LENGTH2));
             return true;
         }
-        if (e.s == "dot" && args.size() == 2) {
-            append(out.x, args[0].comp(0)); append(out.x, args[1].comp(0)); out.x.push_back(law_op(LAW_MUL));
-            if (any_vec) {
-                append(out.x, args[0].comp(1)); append(out.x, args[1].comp(1)); out.x.push_back(law_op(LAW_MUL));
-                out.x.push_back(law_op(LAW_ADD));
+        if (e.s == "dot" && args.size() == 2) {   // the products summed left to right
+            for (int k = 0; k < dim; ++k) {
+                append(out.c[0], args[0].comp(k)); append(out.c[0], args[1].comp(k)); out.c[0].push_back(law_op(LAW_MUL));
+                if (k) out.c[0].push_back(law_op(LAW_ADD));
             }
             return true;
         }
-        if (e.s == "normalize" && args.size() == 1 && args[0].vec) {   // v * (1 / length(v))
-            out.vec = true;
-            for (int c = 0; c < 2; ++c) {
-                std::vector<IrLawOp>& dst = c ? out.y : out.x;
-                append(dst, args[0].comp(c));
+        if (e.s == "normalize" && args.size() == 1 && dim == 2) {   // v * (1 / length(v))
+            out.dim = 2;
+            for (int k = 0; k < 2; ++k) {
+                std::vector<IrLawOp>& dst = out.c[k];
+                append(dst, args[0].comp(k));
                 dst.push_back(law_op(LAW_NUM, 1.0f));
-                append(dst, args[0].x); append(dst, args[0].y); dst.push_back(law_op(LAW_CALL2, 0.0f, LF_LENGTH2));
+                append(dst, args[0].c[0]); append(dst, args[0].c[1]); dst.push_back(law_op(LAW_CALL2, 0.0f, LF_LENGTH2));
                 dst.push_back(law_op(LAW_DIV));
                 dst.push_back(law_op(LAW_MUL));
             }
@@ -255,11 +303,10 @@ bool lower_value(const Expr& e, const std::map<std::string, uint32_t>& uslot, bo
         bool ok;
         LawFn f = law_fn(e.s, e.args.size(), ok);
         if (!ok) return false;
-        out.vec = any_vec;                                              // component-wise, scalar arguments broadcast
-        for (int c = 0; c < (out.vec ? 2 : 1); ++c) {
-            std::vector<IrLawOp>& dst = c ? out.y : out.x;
-            for (const LoweredValue& a : args) append(dst, a.comp(c));
-            dst.push_back(law_op(args.size() == 1 ? LAW_CALL1 : args.size() == 2 ? LAW_CALL2 : LAW_CALL3, 0.0f, f));
+        out.dim = dim;                                                  // component-wise, scalar arguments broadcast
+        for (int k = 0; k < out.dim; ++k) {
+            for (const LoweredValue& a : args) append(out.c[k], a.comp(k));
+            out.c[k].push_back(law_op(args.size() == 1 ? LAW_CALL1 : args.size() == 2 ? LAW_CALL2 : LAW_CALL3, 0.0f, f));
         }
         return true;
     }
@@ -272,29 +319,33 @@ bool lower_value(const Expr& e, const std::map<std::string, uint32_t>& uslot, bo
 bool lower_frame_expr(const Expr& e, const std::map<std::string, uint32_t>& uslot, std::vector<IrLawOp>& prog, bool allow_pixel = false)
 {
     LoweredValue v;
-    if (!lower_value(e, uslot, allow_pixel, v) || v.vec) return false;
-    append(prog, v.x);
+    if (!lower_value(e, uslot, allow_pixel, v) || v.vec()) return false;
+    append(prog, v.c[0]);
     return true;
 }
 
 }  // namespace
 
-// Arithmetic is binary64 with the C library's functions, as a JavaScript host would compute a uniform
-// before handing it to the shader (the same convention as the arc timeline).
+// Arithmetic is binary64 with the C library's functions. Two callers, two wordings of the same expression language:
+// wrap_time = true evaluates a stage argument as the shader would (expr.rs:50-144, the WGSL wording: `time` is the
+// wrapped f32 the shader sees, round() goes to the nearest integer with ties to even); wrap_time = false evaluates a
+// modulation as the page's JavaScript would (expr.rs:147-260: raw u_time, Math.round = floor(x + 0.5)). `%` is the
+// exact truncated remainder in both.
 double eval_frame_prog(const std::vector<IrLawOp>& prog, const float* row, bool wrap_time)
 {
-    auto call = [](uint32_t fn, double a, double b, double c) -> double {
+    auto call = [wrap_time](uint32_t fn, double a, double b, double c) -> double {
         switch (fn) {
         case LF_SIN: return sin(a); case LF_COS: return cos(a); case LF_TAN: return tan(a); case LF_ABS: return fabs(a);
         case LF_SQRT: return sqrt(a); case LF_EXP: return exp(a); case LF_LOG: return log(a); case LF_FLOOR: return floor(a);
         case LF_CEIL: return ceil(a); case LF_FRACT: return a - floor(a); case LF_SIGN: return a > 0.0 ? 1.0 : a < 0.0 ? -1.0 : 0.0;
-        case LF_EXP2: return exp2(a); case LF_LOG2: return log2(a); case LF_ROUND: return nearbyint(a);
-        case LF_MOD: return a - b * trunc(a / b); case LF_ATAN2: return atan2(a, b); case LF_LENGTH2: return sqrt(a * a + b * b);
+        case LF_EXP2: return exp2(a); case LF_LOG2: return log2(a); case LF_ROUND: return wrap_time ? nearbyint(a) : floor(a + 0.5);
+        case LF_MOD: return fmod(a, b); case LF_ATAN2: return atan2(a, b); case LF_LENGTH2: return sqrt(a * a + b * b);
         case LF_MIN: return a < b ? a : b; case LF_MAX: return a > b ? a : b; case LF_POW: return pow(a, b);
         case LF_STEP: return b < a ? 0.0 : 1.0;
         case LF_CLAMP: { double lo = a > b ? a : b; return lo < c ? lo : c; }
         case LF_MIX: return a * (1.0 - c) + b * c;
         case LF_SMOOTHSTEP: { double t = (c - a) / (b - a); t = t < 0.0 ? 0.0 : t > 1.0 ? 1.0 : t; return t * t * (3.0 - 2.0 * t); }
+        case LF_SELECT: return (a != 0.0 && a == a) ? b : c;
         default: return 0.0;
         }
     };
@@ -327,7 +378,7 @@ double eval_frame_prog(const std::vector<IrLawOp>& prog, const float* row, bool 
         default: break;
         }
     }
-    return sp >= 1 ? st[0] : 0.0;
+    return sp >= 1 ? st[sp - 1] : 0.0;
 }
 
 // Stage-argument values: `time` is the f32 value the shader itself sees (u_time wrapped to [0,120));
@@ -441,6 +492,12 @@ Ir lower_cinematic(const Cinematic& c)
     std::map<std::string, uint32_t> uslot;
     for (uint32_t i = 0; i < ir.uniforms.size(); ++i) uslot[ir.uniforms[i].name] = i;
 
+    std::set<std::string> declared_params;   // names the cinematic declares as layer parameters
+    for (const Layer& l : c.layers) {
+        if (!l.is_pipeline) for (const Param& p : l.params) declared_params.insert(p.name);
+        for (const Param& p : l.opts) declared_params.insert(p.name);
+    }
+
     // one stage call -> builtin id + resolved arguments (stages.rs:8-42)
     auto lower_stage = [&](const Stage& s, const Builtin* b) {
         IrStage is;
@@ -491,6 +548,39 @@ Ir lower_cinematic(const Cinematic& c)
                     if (lower_frame_expr(*t.dropped, uslot, d.prog, true) && d.prog.size() < 120 && ir.pixel_exprs.size() < 0xfffe) {
                         d.text = expr_source_text(*t.dropped);
                         a.pixel = (int)ir.pixel_exprs.size();
+                        ir.pixel_exprs.push_back(std::move(d));
+                    }
+                }
+            }
+        }
+        // A colour where three scalars are expected (`tint(gold)`, `shade(mix(ember, frost, audio.bass))`,
+        // `tint(uv.x > 0.0 ? gold : [0.2, 0.3, 0.9])`): the stage's only argument lands on `r` of an (r, g, b)
+        // parameter list and is vec3-valued by the expression compiler's wording (expr.rs:60-81: colour names and
+        // three-element arrays are vec3f). The reference's emitters see one scalar there - a name becomes a uniform
+        // that defaults to 0, anything else the default of `r` - and that stays the resolved argument; the three
+        // components are kept beside it as expression values, which a renderer that animates arguments reads instead.
+        // A name the cinematic declares as a parameter is that parameter, not a colour.
+        if ((b->id == B_TINT || b->id == B_SHADE) && s.args.size() == 1 && (!s.args[0].named || s.args[0].name == "r")) {
+            const Expr& ex = s.args[0].value;
+            const bool bare_colour = ex.kind == Expr::Ident && named_color(ex.s) && !declared_params.count(ex.s);
+            if (bare_colour || (ex.kind != Expr::Number && ex.kind != Expr::Ident && ex.kind != Expr::Dotted)) {
+                LoweredValue v;
+                if (lower_value(ex, uslot, false, v) && v.dim == 3 && v.c[0].size() < 48 && v.c[1].size() < 48 && v.c[2].size() < 48 &&
+                    ir.derived.size() + 3 < 0xfffe) {
+                    for (int k = 0; k < 3; ++k) {
+                        IrDerived d;
+                        d.prog = v.c[k];
+                        d.text = expr_source_text(ex) + "." + "rgb"[k];
+                        is.args[k].derived = (int)ir.derived.size();
+                        ir.derived.push_back(std::move(d));
+                    }
+                } else if (lower_value(ex, uslot, true, v) && v.dim == 3 && v.c[0].size() < 120 && v.c[1].size() < 120 && v.c[2].size() < 120 &&
+                           ir.pixel_exprs.size() + 3 < 0xfffe) {
+                    for (int k = 0; k < 3; ++k) {
+                        IrDerived d;
+                        d.prog = v.c[k];
+                        d.text = expr_source_text(ex) + "." + "rgb"[k];
+                        is.args[k].pixel = (int)ir.pixel_exprs.size();
                         ir.pixel_exprs.push_back(std::move(d));
                     }
                 }
@@ -870,7 +960,7 @@ struct BlobReader {
 bool finite32(float f) { return f - f == 0.0f; }
 
 // A reverse Polish program is usable when every operation is known, finds its operands on the stack, the stack stays
-// within the evaluators' depth and exactly the result is what is left on top. frame_floats: slots of a frame row it may
+// within the evaluators' depth and the result is the one value left on it at the end. frame_floats: slots of a frame row it may
 // read (0 = none, a gravity force law); pixel: it may read p / uv.
 bool prog_well_formed(const std::vector<IrLawOp>& prog, uint32_t frame_floats, bool pixel, bool gravity)
 {
@@ -887,14 +977,14 @@ bool prog_well_formed(const std::vector<IrLawOp>& prog, uint32_t frame_floats, b
         // a call names a function of that many arguments
         case LAW_CALL1: need = 1; if (!(o.fn <= LF_SIGN || (o.fn >= LF_EXP2 && o.fn <= LF_ROUND))) return false; break;
         case LAW_CALL2: need = 2; if (!((o.fn >= LF_MIN && o.fn <= LF_STEP) || (o.fn >= LF_MOD && o.fn <= LF_LENGTH2))) return false; break;
-        case LAW_CALL3: need = 3; if (!(o.fn >= LF_CLAMP && o.fn <= LF_SMOOTHSTEP)) return false; break;
+        case LAW_CALL3: need = 3; if (!((o.fn >= LF_CLAMP && o.fn <= LF_SMOOTHSTEP) || o.fn == LF_SELECT)) return false; break;
         default: return false;
         }
         if (sp < need) return false;
         sp = sp - need + 1;
         if (sp > 60) return false;
     }
-    return prog.empty() || sp >= 1;
+    return prog.empty() || sp == 1;
 }
 
 bool read_prog(BlobReader& r, uint32_t n, std::vector<IrLawOp>& prog)

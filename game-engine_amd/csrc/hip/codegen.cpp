@@ -69,7 +69,7 @@ std::string rpn_expr(const std::vector<IrLawOp>& prog, bool gravity)
         }
         case LAW_CALL3: {
             auto c = pop(), b = pop(), a = pop();
-            const char* f = o.fn == LF_CLAMP ? "gd_clamp" : o.fn == LF_MIX ? "gd_mix" : "gd_smoothstep";
+            const char* f = o.fn == LF_CLAMP ? "gd_clamp" : o.fn == LF_MIX ? "gd_mix" : o.fn == LF_SELECT ? "gd_select" : "gd_smoothstep";
             st.push_back(std::string(f) + "(" + a + ", " + b + ", " + c + ")");
             break;
         }
@@ -454,12 +454,14 @@ static std::string gravity_kernel_body(const Ir& ir, const char* name, unsigned 
     k += "    }\n";
     // Inner loop over one LDS tile, in three builds. dist = max(length(diff), 0.001) is computed as
     // sqrt(max(d2, c)) with c = 0x1.0c6f7ap-20, the smallest float whose correctly rounded root is
-    // 0.001f (sqrt is monotonic, so both forms agree for every d2, NaN included); the short exact
-    // sqrt / reciprocal sequences apply because c <= max(d2, c) < inf whenever d2 is not +inf.
+    // 0.001f (sqrt is monotonic, so both forms agree for every d2, NaN included), and 1 / dist as
+    // inversesqrt(max(d2, c)), rounded once from the exact value (gd_rsqrt_core: the same float on a CPU); the short
+    // exact sequences apply because c <= max(d2, c) < inf whenever d2 is not +inf. A force law that does not read
+    // `dist` (the default rule 1.0) never computes the root.
     //   check_inf : some position of the tile or of this workgroup is NaN or beyond 2^60, so d2 may be
     //               +inf: keep the IEEE results for that case (dist = inf, 1 / dist = 0)
     //   check_self: the tile overlaps this workgroup's own particles (the j == idx term is skipped)
-    // The fast build replaces root and reciprocal by one v_rsq_f32 (about 1 ulp each instead of correctly rounded).
+    // The fast build takes root and reciprocal root from one bare v_rsq_f32 (about 1 ulp each instead of correctly rounded).
     auto tile_loop = [&](bool check_self, bool check_inf) {
         std::string b;
         b += "#pragma unroll GD_GRAV_UNROLL\n";
@@ -470,10 +472,10 @@ static std::string gravity_kernel_body(const Ir& ir, const char* name, unsigned 
         b += "                const float d2 = __builtin_fmaf(dx, dx, dy * dy);\n";
         b += "                float root, rinv;\n";
         if (fast) {
-            b += "                const float d2c = gd_max(d2, 0x1.0c6f7ap-20f);\n";
+            b += "                const float d2c = gd_max(d2, d2_floor);\n";
             b += "                rinv = __builtin_amdgcn_rsqf(d2c); root = d2c * rinv;\n";
         } else {
-            b += "                gd_sqrt_rcp_core(gd_max(d2, 0x1.0c6f7ap-20f), root, rinv);\n";
+            b += "                gd_sqrt_rsqrt_core(gd_max(d2, d2_floor), root, rinv);\n";
         }
         if (check_inf) {
             b += "                const bool finite = d2 < __builtin_inff() || d2 != d2;\n";
@@ -483,21 +485,26 @@ static std::string gravity_kernel_body(const Ir& ir, const char* name, unsigned 
             b += "                const float dist = root;\n";
             b += "                const float inv = rinv;\n";
         }
-        b += "                const float dirx = dx * inv, diry = dy * inv;\n";
+        // force += dir * law with dir = diff / dist, evaluated as diff * (law / dist): one product law * (1 / dist), then
+        // one fused multiply-add per component (with the default law 1.0 the product is the reciprocal root itself)
         b += "                const float f = " + rpn_expr(ir.gravity.law, true) + ";\n";
+        b += "                const float fs = inv * f;\n";
         if (check_self) {
             b += "                const bool self = (base + t) == idx[q];\n";
-            b += "                fx[q] = self ? fx[q] : __builtin_fmaf(dirx, f, fx[q]);\n";
-            b += "                fy[q] = self ? fy[q] : __builtin_fmaf(diry, f, fy[q]);\n";
+            b += "                fx[q] = self ? fx[q] : __builtin_fmaf(dx, fs, fx[q]);\n";
+            b += "                fy[q] = self ? fy[q] : __builtin_fmaf(dy, fs, fy[q]);\n";
         } else {
-            b += "                fx[q] = __builtin_fmaf(dirx, f, fx[q]);\n";
-            b += "                fy[q] = __builtin_fmaf(diry, f, fy[q]);\n";
+            b += "                fx[q] = __builtin_fmaf(dx, fs, fx[q]);\n";
+            b += "                fy[q] = __builtin_fmaf(dy, fs, fy[q]);\n";
         }
         b += "                (void)dist;\n";
         b += "                }\n";
         b += "            }\n";
         return b;
     };
+    // the floor of the squared distance: a literal, or (GD_GRAV_FLOOR_SGPR, a tuning hook) the same value read from the
+    // launch parameters, which keeps it in a scalar register instead of a 32-bit literal in every v_max_f32
+    k += "#ifdef GD_GRAV_FLOOR_SGPR\n    const float d2_floor = __builtin_bit_cast(float, P.floor_bits);\n#else\n    const float d2_floor = 0x1.0c6f7ap-20f;\n#endif\n";
     k += "    const gd_u32 wg_first = P.first + wg_local;\n";
     k += "    for (gd_u32 base = 0; base < P.n; base += 256u) {\n";
     k += "        const gd_u32 j0 = base + threadIdx.x;\n";
@@ -538,7 +545,7 @@ std::string generate_gravity_kernel(const Ir& ir, bool fast)
     k += "struct GameGravityParams {\n"
          "    const float* xin; const float* yin;\n"
          "    float* xout; float* yout; float* vx; float* vy;\n"
-         "    gd_u32 n, first, count, pad;\n"
+         "    gd_u32 n, first, count, floor_bits;\n"
          "    float dt, time;\n"
          "};\n\n";
     // Positions of all n particles stream through LDS in tiles of 256 and every lane walks j = 0..n-1 in index order

@@ -13,7 +13,7 @@ using namespace game;
 namespace {
 
 enum EvalOp { EV_FRACT = 0, EV_SIN, EV_COS, EV_ATAN2, EV_HASH2, EV_NOISE2, EV_SIMPLEX, EV_VORONOI, EV_EXP2, EV_LOG2, EV_POW,
-              EV_MAX, EV_MIN, EV_FBM6, EV_SQRT, EV_DIV, EV_SMOOTHSTEP_GLOW, EV_MOD, EV_UNORM8, EV_NOISE2_LUT, EV_FBM6_LUT, EV_VORONOI_LUT, EV_SIMPLEX_LUT, EV_PACK_UNORM8, EV_COUNT };
+              EV_MAX, EV_MIN, EV_FBM6, EV_SQRT, EV_DIV, EV_SMOOTHSTEP_GLOW, EV_MOD, EV_UNORM8, EV_NOISE2_LUT, EV_FBM6_LUT, EV_VORONOI_LUT, EV_SIMPLEX_LUT, EV_PACK_UNORM8, EV_RSQRT, EV_COUNT };
 
 // Fills the lattice-hash table: entry (row iy + 512, column ix + 512) = {hash2(ix, iy), hash2(ix, iy + 1)}.
 __global__ void hash_lut_fill(float* __restrict__ table)
@@ -78,14 +78,34 @@ __global__ void eval_kernel(int op, uint32_t n, const float* __restrict__ a, con
     case EV_VORONOI_LUT: r = gd_voronoi2d_lut(x, y, 5.0f, lut); break;
     case EV_SIMPLEX_LUT: r = gd_simplex2d(x, y, lut); break;
     case EV_PACK_UNORM8: r = (float)(gd_pack_rgba8(x, 0.0f, 0.0f, 0.0f) & 0xffu); break;
+    case EV_RSQRT: r = (x >= 0x1p-100f && x < __builtin_inff()) ? gd_rsqrt_core(x) : 1.0f / __builtin_sqrtf(x); break;
     default: break;
     }
     out[i] = r;
 }
 
+// inversesqrt as the render path defines it for 2^-100 <= x < inf, decided in exact arithmetic: the exact 1 / sqrt(x)
+// rounded to nearest, except that the float two below a power of four, 4^k (1 - 2^-23), gives 2^-k (see gd_rsqrt_core).
+// The binary64 quotient is within two binary64 ulps of the exact value, so the binary32 at or below it (a) and the next
+// one (b) bracket the exact value; with m = (a + b) / 2 (25 significant bits: m * m is exact in binary64) the sign of
+// the fused x * m^2 - 1 says on which side of the midpoint the exact value lies. A tie cannot occur.
+__device__ float rsqrt_arbitrated(float x)
+{
+    if ((gd_bits(x) & 0x00ffffffu) == 0x007ffffeu)   // 4^k (1 - 2^-23), biased exponent E = 2 k + 126: the result is 2^-k
+        return gd_from_bits((127u - ((gd_bits(x) >> 23) - 126u) / 2u) << 23);
+    const double xd = (double)x;
+    const double yd = 1.0 / __builtin_sqrt(xd);
+    float a = (float)yd;
+    if ((double)a > yd) a = gd_from_bits(gd_bits(a) - 1u);
+    const float b = gd_from_bits(gd_bits(a) + 1u);
+    const double m = 0.5 * ((double)a + (double)b);
+    return __builtin_fma(xd, m * m, -1.0) > 0.0 ? a : b;
+}
+
 // which: 0 = fract(x) for every bit pattern x; 1 = max(x, c), 2 = min(x, c) for every x and the
-// probe constants below; 3 = gd_sqrt(x), 4 = gd_rcp(x) against the compiler's IEEE expansions; 5 = gd_sqrt_rcp_core
-// against sqrtf(x) and 1 / sqrtf(x) for 2^-100 <= x < inf.
+// probe constants below; 3 = gd_sqrt(x), 4 = gd_rcp(x) against the compiler's IEEE expansions; 5 = gd_sqrt_rsqrt_core
+// against sqrtf(x) and the exactly arbitrated 1 / sqrt(x) for 2^-100 <= x < inf; 6 = v_cvt_pk_u8_f32 against the frame
+// store's definition; 7 = gd_rsqrt_core alone against the same arbitrated value.
 __global__ void exhaustive_kernel(int which, unsigned long long* mismatches, uint32_t* first_bad)
 {
     const float probes[6] = {0.0f, -0.0f, 1.0f, -1.0f, __builtin_inff(), __builtin_nanf("")};
@@ -109,12 +129,14 @@ __global__ void exhaustive_kernel(int which, unsigned long long* mismatches, uin
             gd_u32 want = (x != x || !(t > 0.0f)) ? 0u : (t >= 255.0f ? 255u : (gd_u32)t);
             gd_u32 lo = __builtin_amdgcn_cvt_pk_u8_f32(x, 0u, 0u), mid = __builtin_amdgcn_cvt_pk_u8_f32(x, 2u, 0xffffffffu);
             if (lo != want || mid != (0xff00ffffu | (want << 16))) { ++bad; atomicMin(first_bad, (gd_u32)v); }
-        } else if (which == 5) {
+        } else if (which == 5 || which == 7) {
             if (!(x >= 0x1p-100f && x < __builtin_inff())) continue;
-            float root, inv;
-            gd_sqrt_rcp_core(x, root, inv);
-            float want_root = __builtin_sqrtf(x), want_inv = 1.0f / want_root;
-            if (gd_bits(root) != gd_bits(want_root) || gd_bits(inv) != gd_bits(want_inv)) { ++bad; atomicMin(first_bad, (gd_u32)v); }
+            const float want_inv = rsqrt_arbitrated(x);
+            if (which == 5) {
+                float root, inv;
+                gd_sqrt_rsqrt_core(x, root, inv);
+                if (gd_bits(root) != gd_bits(__builtin_sqrtf(x)) || gd_bits(inv) != gd_bits(want_inv)) { ++bad; atomicMin(first_bad, (gd_u32)v); }
+            } else if (gd_bits(gd_rsqrt_core(x)) != gd_bits(want_inv)) { ++bad; atomicMin(first_bad, (gd_u32)v); }
         } else {
             for (int p = 0; p < 6; ++p) {
                 float c = probes[p];
@@ -199,7 +221,14 @@ int lut_for_current_device(int kind, const float** table)
 
 extern "C" {
 
-int game_hip_shutdown(void) { return release_device_tables(); }
+int game_hip_shutdown(void)
+{
+    // live contexts hold raw pointers into the tables: freeing them now would leave those contexts reading freed memory
+    const int live = live_context_count();
+    if (live > 0)
+        return set_error(GAME_E_ARGUMENT, "game_hip_shutdown: " + std::to_string(live) + " render context(s) still exist; destroy them first");
+    return release_device_tables();
+}
 
 int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out)
 {
@@ -223,7 +252,7 @@ int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out
 
 int game_hip_check_exhaustive(int which, uint64_t* mismatches, uint32_t* first_bad)
 {
-    if (which < 0 || which > 6 || !mismatches || !first_bad) return set_error(GAME_E_ARGUMENT, "game_hip_check_exhaustive: bad argument");
+    if (which < 0 || which > 7 || !mismatches || !first_bad) return set_error(GAME_E_ARGUMENT, "game_hip_check_exhaustive: bad argument");
     DevBuf dm, df;
     HIP_TRY(dm.alloc(8));
     HIP_TRY(df.alloc(4));

@@ -41,24 +41,35 @@ GD float gd_sqrt_core(float x)
     float d = __builtin_fmaf(-g, g, x);
     return __builtin_fmaf(d, h, g);
 }
-// Root and its reciprocal together, for c <= x < inf with c >= 2^-100: the reciprocal of the ROUNDED root
-// is refined from the same v_rsq_f32 value by one Newton step, which is the correctly rounded 1 / root
-// for every x except when the root's significand is all ones (1 / root then lies just above a power
-// of two and the step lands one ulp low); that case adds the ulp back. Checked against 1.0f / sqrtf(x)
-// over all inputs by game_hip_check_exhaustive(5).
-GD void gd_sqrt_rcp_core(float x, float& root, float& inv)
+// inversesqrt(x) for 2^-100 <= x < inf: the exact 1 / sqrt(x) rounded ONCE to the nearest float, which is what makes it
+// the same float on any machine - with one stated exception: for x two floats below a power of four,
+// x = 4^k (1 - 2^-23), the exact value lies 4.5e-8 ulp above the midpoint of 2^-k and its upper neighbour, and the
+// result is 2^-k (an error of 0.50000005 ulp instead of at most 0.5). From the v_rsq_f32 value y0 (within one ulp) one
+// Newton step y0 + (y0 / 2)(1 - x y0^2) whose residual is exact to the last bit that matters: t = x y0 rounded, te its
+// rounding error (exact through fma), so 1 - x y0^2 = (1 - t y0) - te y0. In the excepted class y0 = 2^-k, the residual is
+// exactly 2^-23 and the step lands on the midpoint itself, which rounds to the even neighbour 2^-k. Seven instructions
+// with the v_rsq_f32; checked against that definition, decided in exact arithmetic, over every input of the range by
+// game_hip_check_exhaustive(5) and (7).
+GD float gd_rsqrt_core(float x)
 {
-    float r = __builtin_amdgcn_rsqf(x);
-    float g = x * r, h = 0.5f * r;
-    float d = __builtin_fmaf(-g, g, x);
-    g = __builtin_fmaf(d, h, g);
-    float e = __builtin_fmaf(-g, r, 1.0f);
-    float y = __builtin_fmaf(e, r, r);
-#ifndef GD_NO_ONES_FIX
-    gd_u32 ones = (gd_bits(g) & 0x7fffffu) == 0x7fffffu ? 1u : 0u;
-    y = gd_from_bits(gd_bits(y) + ones);
-#endif
-    root = g; inv = y;
+    float y0 = __builtin_amdgcn_rsqf(x);
+    float t = x * y0, h = 0.5f * y0;
+    float te = __builtin_fmaf(x, y0, -t);
+    float e = __builtin_fmaf(-t, y0, 1.0f);
+    e = __builtin_fmaf(-te, y0, e);
+    return __builtin_fmaf(h, e, y0);
+}
+// Root (correctly rounded) and reciprocal root (as gd_rsqrt_core) together, from the same v_rsq_f32 value: eleven instructions.
+GD void gd_sqrt_rsqrt_core(float x, float& root, float& inv)
+{
+    float y0 = __builtin_amdgcn_rsqf(x);
+    float t = x * y0, h = 0.5f * y0;
+    float d = __builtin_fmaf(-t, t, x);
+    root = __builtin_fmaf(d, h, t);
+    float te = __builtin_fmaf(x, y0, -t);
+    float e = __builtin_fmaf(-t, y0, 1.0f);
+    e = __builtin_fmaf(-te, y0, e);
+    inv = __builtin_fmaf(h, e, y0);
 }
 // The short sequences and the IEEE expansions agree wherever the short ones are valid, so the choice could
 // be made per wave instead of per lane (one scalar branch on "every active lane is in range"). Measured on
@@ -106,6 +117,9 @@ GD float gd_smoothstep(float e0, float e1, float x)
     return t * t * __builtin_fmaf(-2.0f, t, 3.0f);
 }
 GD float gd_length2(float x, float y) { return gd_sqrt(__builtin_fmaf(x, x, y * y)); }
+// `c ? t : f` of a stage-argument expression (expr.rs:132-142 words it select(f, t, c)): c is the 0 / 1 a comparison
+// leaves, or any number - non-zero and not NaN counts as true
+GD float gd_select(float c, float t, float f) { return (c != 0.0f && c == c) ? t : f; }
 
 // ── sin / cos / atan ────────────────────────────────────────────────────────────────────
 // GLSL does not fix the precision of these; the render path uses a fixed algorithm made of
@@ -536,12 +550,13 @@ GD void gd_project_led(float vx, float count, float& ox, float& oy)             
     oy = 0.5f;
 }
 
-// length(uv) and its reciprocal, both correctly rounded, once per pixel: vignette and chromatic (and their WebGPU
-// wordings) all start from length(uv), and normalize(uv) is uv * (1 / length(uv)). uv = 0 gives 0 and +inf.
+// length(uv) and 1 / length(uv), once per pixel: vignette and chromatic (and their WebGPU wordings) all start from
+// length(uv), and normalize(uv) is uv * inversesqrt(dot(uv, uv)). For d2 = dot(uv, uv) in [2^-100, inf) they are the correctly
+// rounded root and gd_rsqrt_core; outside that range (uv = 0 among them: 0 and +inf) sqrt(d2) and 1 / sqrt(d2).
 GD void gd_uv_length(GdPix& s)
 {
     const float d2 = __builtin_fmaf(s.uvx, s.uvx, s.uvy * s.uvy);
-    if (gd_wave_all(d2 >= 0x1p-100f && d2 < __builtin_inff())) gd_sqrt_rcp_core(d2, s.uvlen, s.uvinv);
+    if (gd_wave_all(d2 >= 0x1p-100f && d2 < __builtin_inff())) gd_sqrt_rsqrt_core(d2, s.uvlen, s.uvinv);
     else { s.uvlen = __builtin_sqrtf(d2); s.uvinv = 1.0f / s.uvlen; }
 }
 

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -79,10 +80,16 @@ struct game_hip_ctx {
     // game_hip_render_into: this device's static scratch array (not owned), a page-locked staging buffer of the same
     // size made at creation, and the event that says the last copy out of the staging buffer has finished
     float* scratch = nullptr;
+    hipEvent_t ev_scratch = nullptr;   // this device's "last reader of the scratch array" event (shared, not owned)
     float* stage_host = nullptr;
     hipEvent_t ev_stage = nullptr;
     bool stage_busy = false;
 };
+
+namespace game {
+static std::atomic<int> g_live_contexts{0};
+int live_context_count() { return g_live_contexts.load(); }
+}  // namespace game
 
 namespace {
 
@@ -101,9 +108,11 @@ struct FrameParams {
 struct GravityParams {
     const float* xin; const float* yin;
     float* xout; float* yout; float* vx; float* vy;
-    uint32_t n, first, count, pad;
+    uint32_t n, first, count, floor_bits;   // floor_bits: 0x1.0c6f7ap-20f, the floor of the squared pair distance
     float dt, time;
 };
+
+const uint32_t kGravityLaunchParticles = 1u << 20;   // particles integrated per launch of the gravity kernel (a multiple of 512)
 
 double now_ms()
 {
@@ -543,6 +552,7 @@ int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int d
     if (device < 0 || device >= ndev) return set_error(GAME_E_ARGUMENT, "game_hip_create: device ordinal out of range");
     HIP_TRY(hipSetDevice(device));
     auto* c = new game_hip_ctx;
+    ++g_live_contexts;   // game_hip_destroy, which every failure path below goes through, takes it back
     c->ir = *ir->ir;
     c->device = device;
     c->w = width; c->h = height;
@@ -555,7 +565,7 @@ int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int d
     double t0 = now_ms();
     int rc = compile_hip(c->source, "game_frame.hip", code);
     c->compile_ms = (float)(now_ms() - t0);
-    if (rc) { delete c; return rc; }
+    if (rc) { game_hip_destroy(c); return rc; }
     auto fail = [&](const char* what, hipError_t err) { int r = hip_fail(what, err); game_hip_destroy(c); return r; };
     if ((e = hipModuleLoadData(&c->mod, code.data())) != hipSuccess) return fail("hipModuleLoadData", e);
     if ((e = hipModuleGetFunction(&c->fn, c->mod, "game_frame")) != hipSuccess) return fail("hipModuleGetFunction", e);
@@ -565,7 +575,12 @@ int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int d
     c->ev0 = c->ev_own0; c->ev1 = c->ev_own1;
     if ((e = hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     if ((e = hipHostMalloc((void**)&c->stage_host, GAME_HIP_SCRATCH_BYTES, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
-    { void* sp = nullptr; rc = scratch_for_current_device(&sp); if (rc) { game_hip_destroy(c); return rc; } c->scratch = (float*)sp; }
+    {
+        void* sp = nullptr; void* sev = nullptr;
+        rc = scratch_for_current_device(&sp, &sev);
+        if (rc) { game_hip_destroy(c); return rc; }
+        c->scratch = (float*)sp; c->ev_scratch = (hipEvent_t)sev;
+    }
     rc = ensure_ring(c, c->ir.uses_memory ? 2u : 4u);
     if (rc) { game_hip_destroy(c); return rc; }
     t0 = now_ms();
@@ -628,6 +643,7 @@ void game_hip_destroy(game_hip_ctx* c)
     if (c->gmod) (void)hipModuleUnload(c->gmod);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    --g_live_contexts;
 }
 
 int game_hip_set_ring(game_hip_ctx* c, uint32_t ring_frames)
@@ -663,10 +679,16 @@ int game_hip_render_into(game_hip_ctx* c, const float* uniforms, uint32_t nframe
                                               " bytes, at most " + std::to_string(std::min<size_t>(65535u, GAME_HIP_SCRATCH_BYTES / row_bytes)) +
                                               " frames per call for this cinematic)");
     if (((uintptr_t)rgba8_dev & 15u) != 0) return set_error(GAME_E_ARGUMENT, "game_hip_render_into: the output must be 16-byte aligned");
+    // the frame filter needs the raw frame and a second kernel per frame; this entry point renders unfiltered frames only
+    if (c->blur || c->raw_pending)
+        return set_error(GAME_E_UNSUPPORTED, "game_hip_render_into: the context has a frame filter set (game_hip_set_blur); use game_hip_render");
     HIP_TRY(hipSetDevice(c->device));
     // the staging buffer is free again once the previous call's copy out of it has run
     if (c->stage_busy) { HIP_TRY(hipEventSynchronize(c->ev_stage)); c->stage_busy = false; }
     build_rows(c, uniforms, nframes, c->stage_host);
+    // every context of this GPU stages its rows in the same array: the refill waits (on the device) for the kernels of
+    // whichever context read it last
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_scratch, 0));
     HIP_TRY(hipMemcpyAsync(c->scratch, c->stage_host, (size_t)nframes * row_bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipEventRecord(c->ev_stage, c->stream));
     c->stage_busy = true;
@@ -696,6 +718,7 @@ int game_hip_render_into(game_hip_ctx* c, const float* uniforms, uint32_t nframe
         if (rc) return rc;
         ++c->last_launches;
     }
+    HIP_TRY(hipEventRecord(c->ev_scratch, c->stream));
     if (timed) { HIP_TRY(hipEventRecord(c->ev_own1, c->stream)); c->own_recorded = true; }
     return GAME_OK;
 }
@@ -979,11 +1002,17 @@ int game_hip_particles_step(game_hip_ctx* c, float dt, uint32_t steps, uint32_t 
         P.xin = c->px[c->cur]; P.yin = c->py[c->cur];
         P.xout = c->px[1 - c->cur]; P.yout = c->py[1 - c->cur];
         P.vx = c->vx; P.vy = c->vy;
-        P.n = c->n; P.first = first; P.count = count; P.pad = 0;
+        P.n = c->n; P.first = first; P.count = count; P.floor_bits = 0x358637bdu;
         P.dt = dt; P.time = c->sim_time;
-        void* args[] = {&P};
-        HIP_TRY(hipModuleLaunchKernel(gfn, (count + span - 1u) / span, 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
-        ++c->last_launches;
+        // One launch per 2^20 particles of the range: at 2^24 particles a whole step is about 80 s of GPU time, and a
+        // launch should stay in the seconds. The launches of a step read the same positions and write disjoint ranges.
+        for (uint32_t off = 0; off < count; off += kGravityLaunchParticles) {
+            P.first = first + off;
+            P.count = count - off < kGravityLaunchParticles ? count - off : kGravityLaunchParticles;
+            void* args[] = {&P};
+            HIP_TRY(hipModuleLaunchKernel(gfn, (P.count + span - 1u) / span, 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+            ++c->last_launches;
+        }
         c->cur = 1 - c->cur;
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));

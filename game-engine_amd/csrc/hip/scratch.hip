@@ -12,11 +12,12 @@ static __device__ __align__(256) unsigned char scratch[GAME_HIP_SCRATCH_BYTES];
 
 namespace game {
 
-int scratch_for_current_device(void** ptr)
+int scratch_for_current_device(void** ptr, void** last_reader_event)
 {
     static std::mutex mu;
     static void* per_device[64] = {};
-    if (!ptr) return set_error(GAME_E_ARGUMENT, "scratch_for_current_device: null argument");
+    static hipEvent_t reader[64] = {};
+    if (!ptr || !last_reader_event) return set_error(GAME_E_ARGUMENT, "scratch_for_current_device: null argument");
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return set_error(GAME_E_HIP, std::string("hipGetDevice: ") + hipGetErrorString(e));
@@ -27,9 +28,14 @@ int scratch_for_current_device(void** ptr)
         e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
         if (e != hipSuccess || !p)
             return set_error(GAME_E_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) return set_error(GAME_E_HIP, std::string("hipEventCreate(scratch reader): ") + hipGetErrorString(e));
+        reader[dev] = ev;
         per_device[dev] = p;
     }
     *ptr = per_device[dev];
+    *last_reader_event = (void*)reader[dev];
     return GAME_OK;
 }
 

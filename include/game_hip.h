@@ -183,7 +183,8 @@ enum {
  *            expression-valued stage arguments: numbers, frame-row slots, operators and calls only)
  * Law ops: 0 number(value), 1 dist, 2 simulation time (force laws only), 3 + 4 - 5 * 6 / 7 pow 8 > 9 <, 10 negate,
  * 11 / 12 / 13 call of a 1 / 2 / 3 argument function fn (0 sin cos tan abs sqrt exp log floor ceil fract 10 sign |
- * 11 min max pow 14 step | 15 clamp mix 17 smoothstep | 18 exp2 log2 20 round | 21 mod atan2 23 length(x, y)),
+ * 11 min max pow 14 step | 15 clamp mix 17 smoothstep | 18 exp2 log2 20 round | 21 mod atan2 23 length(x, y) |
+ * 24 select(c, t, f) = c is non-zero and not NaN ? t : f, three arguments), a program leaves exactly one value;
  * 14 frame-row slot fn, 15..18 p.x p.y uv.x uv.y (pixel expressions only).
  * Built-in uniform slot 0 used as a stage argument means the shader's wrapped time
  * `fract(u_time / 120) * 120` (glsl.rs:56), not the raw u_time. */
@@ -249,9 +250,14 @@ int game_hip_render_band(game_hip_ctx* ctx, const float* uniforms, uint32_t nfra
  * makes no hipMalloc / hipFree / hipHostMalloc / event creation; everything it needs was made by game_hip_create. It
  * returns when the work is queued on the context's stream (game_hip_sync waits). Limits: nframes * (frame floats + 2
  * + derived values) * 4 <= 262144 and nframes <= 65535, GAME_E_ARGUMENT beyond. Memory cinematics continue from, and
- * update, the context's feedback state exactly as game_hip_render does. All contexts of one GPU share that GPU's array,
- * which keeps the last call's contents: calls of this entry point that overlap on one GPU (distinct contexts driven
- * concurrently) race on it - serialise them, or use game_hip_render. Inside a timing section the call is not timed. */
+ * update, the context's feedback state exactly as game_hip_render does. A context with a frame filter set
+ * (game_hip_set_blur) is refused with GAME_E_UNSUPPORTED: filtered frames need the raw frame and go through
+ * game_hip_render. All contexts of one GPU share that GPU's array, which keeps the last call's contents. Calls made one
+ * after the other - from one thread, or from several with the caller's own lock - are ordered on the device without a
+ * host wait: each call makes its stream wait for a per-GPU event that the previous call recorded behind its kernels, so
+ * two contexts may alternate without game_hip_sync in between. Calls that overlap in time on one GPU (distinct contexts
+ * driven concurrently from distinct threads) race on the array and on that event - serialise them, or use
+ * game_hip_render. Inside a timing section the call is not timed. */
 int game_hip_render_into(game_hip_ctx* ctx, const float* uniforms, uint32_t nframes, void* rgba8_dev);
 /* Page-locked host memory for the rgba8_host argument: frames then leave the GPU by DMA at PCIe rate
  * instead of through the staged copy a pageable buffer gets (about 4x faster on the tested host). Any host
@@ -331,8 +337,9 @@ int game_hip_particles_time(game_hip_ctx* ctx, float* sim_time);
 int game_hip_particles_set_time(game_hip_ctx* ctx, float sim_time);
 
 /* Releases what the library keeps per device for the life of the process (the lattice tables of game_device.h). Every
- * context must have been destroyed first; later contexts rebuild what they need. The browser counterpart is the page
- * going away. */
+ * context must have been destroyed first - while one exists the call fails with GAME_E_ARGUMENT and frees nothing (a
+ * context holds pointers into those tables); later contexts rebuild what they need. The browser counterpart is the
+ * page going away. */
 int game_hip_shutdown(void);
 
 #ifdef __cplusplus

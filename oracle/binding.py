@@ -30,15 +30,22 @@ class Oracle:
         L.game_oracle_gravity.restype = c.c_int
         L.game_oracle_gravity.argtypes = [c.c_void_p, c.c_size_t, c.c_uint32, c.c_void_p, c.c_float, c.c_uint32,
                                           c.POINTER(c.c_float), c.c_int]
+        L.game_oracle_gravity_range.restype = c.c_int
+        L.game_oracle_gravity_range.argtypes = [c.c_void_p, c.c_size_t, c.c_uint32, c.c_void_p, c.c_float, c.c_float, c.c_uint32,
+                                                c.c_uint32, c.c_void_p, c.c_int]
         L.game_oracle_set_gravity_blocked.restype = None
         L.game_oracle_set_gravity_blocked.argtypes = [c.c_int]
         L.game_oracle_seed_particles.restype = None
         L.game_oracle_seed_particles.argtypes = [c.c_uint32, c.c_uint64, c.c_void_p]
         for name, nargs in (("sin", 1), ("cos", 1), ("atan2", 2), ("fract", 1), ("hash2", 2), ("noise2", 2),
-                            ("simplex2d", 2), ("voronoi2d", 3), ("pow", 2), ("exp", 1), ("log", 1)):
+                            ("simplex2d", 2), ("voronoi2d", 3), ("pow", 2), ("exp", 1), ("log", 1), ("rsqrt", 1)):
             fn = getattr(L, "game_oracle_" + name)
             fn.restype = c.c_float
             fn.argtypes = [c.c_float] * nargs
+        L.game_oracle_rsqrt_array.restype = None
+        L.game_oracle_rsqrt_array.argtypes = [c.c_uint32, c.c_void_p, c.c_void_p]
+        L.game_oracle_rsqrt_selfcheck.restype = c.c_uint32
+        L.game_oracle_rsqrt_selfcheck.argtypes = [c.POINTER(c.c_uint32)]
         L.game_oracle_fbm2.restype = c.c_float
         L.game_oracle_fbm2.argtypes = [c.c_float, c.c_float, c.c_int, c.c_float, c.c_float]
         self.L = L
@@ -75,6 +82,16 @@ class Oracle:
         p = np.zeros((n, 4), dtype=np.float32)
         self.L.game_oracle_seed_particles(n, seed, p.ctypes.data)
         return p
+
+    def gravity_range(self, blob, particles, dt, time, first, count, threads=8, blocked=True):
+        """One step of particles [first, first + count) against all of `particles` ((n, 4) float32, not copied);
+        `time` is the dispatch clock of the step (the clock before it + dt). Returns (count, 4)."""
+        self.L.game_oracle_set_gravity_blocked(1 if blocked else 0)
+        p = np.ascontiguousarray(particles, dtype=np.float32)
+        out = np.empty((count, 4), dtype=np.float32)
+        rc = self.L.game_oracle_gravity_range(blob, len(blob), p.shape[0], p.ctypes.data, dt, time, first, count, out.ctypes.data, threads)
+        assert rc == 0
+        return out
 
     def gravity(self, blob, particles, dt, steps, sim_time=0.0, threads=8, blocked=True):
         """blocked=False forces the one-particle-at-a-time loop even for constant force laws."""

@@ -47,7 +47,7 @@ enum { LAW_NUM = 0, LAW_DIST, LAW_TIME, LAW_ADD, LAW_SUB, LAW_MUL, LAW_DIV, LAW_
        LAW_CALL1, LAW_CALL2, LAW_CALL3, LAW_UNIFORM, LAW_PX, LAW_PY, LAW_UVX, LAW_UVY };
 enum { LF_SIN = 0, LF_COS, LF_TAN, LF_ABS, LF_SQRT, LF_EXP, LF_LOG, LF_FLOOR, LF_CEIL, LF_FRACT, LF_SIGN,
        LF_MIN, LF_MAX, LF_POW, LF_STEP, LF_CLAMP, LF_MIX, LF_SMOOTHSTEP, LF_EXP2, LF_LOG2,
-       LF_ROUND, LF_MOD, LF_ATAN2, LF_LENGTH2 };
+       LF_ROUND, LF_MOD, LF_ATAN2, LF_LENGTH2, LF_SELECT };
 
 #define MAX_PIXEL_EXPRS 256
 typedef struct {
@@ -78,16 +78,17 @@ static int prog_ok(const ir_law* prog, uint32_t n, uint32_t frame_floats, int pi
         case LAW_PX: case LAW_PY: case LAW_UVX: case LAW_UVY: if (!pixel) return 0; break;
         case LAW_ADD: case LAW_SUB: case LAW_MUL: case LAW_DIV: case LAW_POW: case LAW_GT: case LAW_LT: need = 2; break;
         case LAW_NEG: need = 1; break;
-        case LAW_CALL1: need = 1; if (o->fn > LF_LENGTH2) return 0; break;
-        case LAW_CALL2: need = 2; if (o->fn > LF_LENGTH2) return 0; break;
-        case LAW_CALL3: need = 3; if (o->fn > LF_LENGTH2) return 0; break;
+        /* a call names a function of that many arguments */
+        case LAW_CALL1: need = 1; if (!(o->fn <= LF_SIGN || (o->fn >= LF_EXP2 && o->fn <= LF_ROUND))) return 0; break;
+        case LAW_CALL2: need = 2; if (!((o->fn >= LF_MIN && o->fn <= LF_STEP) || (o->fn >= LF_MOD && o->fn <= LF_LENGTH2))) return 0; break;
+        case LAW_CALL3: need = 3; if (!((o->fn >= LF_CLAMP && o->fn <= LF_SMOOTHSTEP) || o->fn == LF_SELECT)) return 0; break;
         default: return 0;
         }
         if (sp < need) return 0;
         sp = sp - need + push;
         if (sp > 60) return 0;
     }
-    return n == 0 || sp >= 1;
+    return n == 0 || sp == 1;   /* the result is the one value left on the stack */
 }
 
 /* Everything the interpreter indexes with a value read from the blob is checked here, once, so that a damaged or
@@ -315,6 +316,7 @@ static float law_call(uint32_t fn, float a, float b, float c)
     case LF_STEP: return gm_step(a, b);
     case LF_CLAMP: return gm_clamp(a, b, c); case LF_MIX: return gm_mix(a, b, c);
     case LF_SMOOTHSTEP: return gm_smoothstep(a, b, c);
+    case LF_SELECT: return (a != 0.0f && a == a) ? b : c;             /* expr.rs:132-142 `c ? t : f` = select(f, t, c) */
     default: return 0.0f;
     }
 }
@@ -718,8 +720,7 @@ static void shade_pixel(const ir_view* ir, const frame_consts* fc, float uvx, fl
                 break;
             }
             case B_CHROMATIC: {                                                                    /* :465-472 */
-                float len = gm_length2(uvx, uvy);
-                float dirx = uvx * gm_rcp(len) * a0;                                               /* normalize(uv) * offset: reciprocal, multiply */
+                float dirx = uvx * gm_rsqrt(fmaf(uvx, uvx, uvy * uvy)) * a0;                       /* normalize(uv) = uv * inversesqrt(dot(uv, uv)) */
                 float r = cr, b = cb;
                 cr = r * (1.0f + dirx);
                 cb = b * (1.0f - dirx);
@@ -906,6 +907,7 @@ typedef struct {
     const float* in;   /* n x {pos.x, pos.y, vel.x, vel.y} */
     float* out;
     uint32_t n, begin, end;
+    uint32_t out_base;   /* particle idx is written to out[4 * (idx - out_base)] */
     float dt, time;
 } grav_job;
 
@@ -918,11 +920,14 @@ static void gravity_range(const grav_job* J)
         for (uint32_t j = 0; j < J->n; j++) {                                   /* gravity.rs:78-89 */
             if (j == idx) continue;
             float dx = J->in[4 * j] - sx, dy = J->in[4 * j + 1] - sy;
-            float dist = gm_max(gm_length2(dx, dy), 0.001f);
-            float inv = gm_rcp(dist);                                           /* dir = diff / dist: one reciprocal */
-            float dirx = dx * inv, diry = dy * inv;
+            float d2 = fmaf(dx, dx, dy * dy);
+            float dist = gm_max(sqrtf(d2), 0.001f);
+            /* dir = diff / dist as diff * inversesqrt(max(d2, c)), c = the smallest float whose root rounds to 0.001f
+             * (so sqrt(max(d2, c)) is dist for every d2): the reciprocal root is rounded once */
+            float inv = gm_rsqrt(gm_max(d2, 0x1.0c6f7ap-20f));
             float f = eval_law(ir->law, ir->h->n_law, dist, J->time);
-            fx = fmaf(dirx, f, fx); fy = fmaf(diry, f, fy);                     /* contraction point */
+            float fs = inv * f;                                                 /* force += dir * law as diff * (law / dist) */
+            fx = fmaf(dx, fs, fx); fy = fmaf(dy, fs, fy);                       /* contraction point */
         }
         float vx = J->in[4 * idx + 2] * ir->h->damping + fx * J->dt;            /* gravity.rs:92-96 */
         float vy = J->in[4 * idx + 3] * ir->h->damping + fy * J->dt;
@@ -936,19 +941,43 @@ static void gravity_range(const grav_job* J)
             px = gm_fract((px + 1.0f) * 0.5f) * 2.0f - 1.0f;
             py = gm_fract((py + 1.0f) * 0.5f) * 2.0f - 1.0f;
         }
-        J->out[4 * idx] = px; J->out[4 * idx + 1] = py; J->out[4 * idx + 2] = vx; J->out[4 * idx + 3] = vy;
+        J->out[4 * (idx - J->out_base)] = px; J->out[4 * (idx - J->out_base) + 1] = py; J->out[4 * (idx - J->out_base) + 2] = vx; J->out[4 * (idx - J->out_base) + 3] = vy;
     }
 }
 /* The same loop for a force law that is one constant (the default rule 1.0), eight particles side by side: each of
- * them walks j in the same order through the same correctly rounded operations (sqrtf, 1 / x, fmaf), so every
+ * them walks j in the same order through the same correctly rounded operations (inversesqrt, fmaf), so every
  * particle gets the bits gravity_range gives it; written with AVX2 / FMA vector operations, each of which is the
  * IEEE operation of its scalar counterpart in every lane.
- * max(d, 0.001) is written as a select: a NaN distance yields 0.001 as gm_max does, and d is never negative. */
+ * max(d2, c) is written as a select: a NaN d2 yields c as gm_max does, and d2 is never negative. */
 #define GRAV_BLOCK 8
+/* gm_rsqrt on eight floats. The binary64 quotient rounded to binary32 is the correctly rounded result unless it lies
+ * within a few binary64 ulps of the midpoint of two floats; a block with such a lane, with a lane outside
+ * [2^-100, inf), or with a lane of the excepted class 4^k (1 - 2^-23) goes through the scalar function lane by lane. */
+static inline __m256 gm_rsqrt8(__m256 x)
+{
+    const __m256d one = _mm256_set1_pd(1.0);
+    const __m256d y0 = _mm256_div_pd(one, _mm256_sqrt_pd(_mm256_cvtps_pd(_mm256_castps256_ps128(x))));
+    const __m256d y1 = _mm256_div_pd(one, _mm256_sqrt_pd(_mm256_cvtps_pd(_mm256_extractf128_ps(x, 1))));
+    const __m256i mask = _mm256_set1_epi64x(0x1fffffff), lo = _mm256_set1_epi64x(0x0ffffff7), hi = _mm256_set1_epi64x(0x10000009);
+    const __m256i l0 = _mm256_and_si256(_mm256_castpd_si256(y0), mask), l1 = _mm256_and_si256(_mm256_castpd_si256(y1), mask);
+    const __m256i near0 = _mm256_and_si256(_mm256_cmpgt_epi64(l0, lo), _mm256_cmpgt_epi64(hi, l0));
+    const __m256i near1 = _mm256_and_si256(_mm256_cmpgt_epi64(l1, lo), _mm256_cmpgt_epi64(hi, l1));
+    const __m256 in_range = _mm256_and_ps(_mm256_cmp_ps(x, _mm256_set1_ps(0x1p-100f), _CMP_GE_OQ), _mm256_cmp_ps(x, _mm256_set1_ps(INFINITY), _CMP_LT_OQ));
+    const __m256i xb = _mm256_castps_si256(x);
+    const __m256i excepted = _mm256_cmpeq_epi32(_mm256_and_si256(xb, _mm256_set1_epi32(0x00ffffff)), _mm256_set1_epi32(0x007ffffe));
+    if (_mm256_movemask_ps(in_range) != 0xff || !_mm256_testz_si256(_mm256_or_si256(near0, near1), _mm256_set1_epi64x(-1)) ||
+        !_mm256_testz_si256(excepted, excepted)) {
+        float v[8];
+        _mm256_storeu_ps(v, x);
+        for (int k = 0; k < 8; k++) v[k] = gm_rsqrt(v[k]);
+        return _mm256_loadu_ps(v);
+    }
+    return _mm256_set_m128(_mm256_cvtpd_ps(y1), _mm256_cvtpd_ps(y0));
+}
 static void gravity_range_const(const grav_job* J, float f)
 {
     const ir_view* ir = J->ir;
-    const __m256 vf = _mm256_set1_ps(f), vmin = _mm256_set1_ps(0.001f), one = _mm256_set1_ps(1.0f);
+    const __m256 vf = _mm256_set1_ps(f), vc = _mm256_set1_ps(0x1.0c6f7ap-20f);
     for (uint32_t i0 = J->begin; i0 < J->end; i0 += GRAV_BLOCK) {
         uint32_t id[GRAV_BLOCK];
         float sx[GRAV_BLOCK], sy[GRAV_BLOCK], fx[GRAV_BLOCK], fy[GRAV_BLOCK];
@@ -962,10 +991,11 @@ static void gravity_range_const(const grav_job* J, float f)
         __m256 vfx = _mm256_setzero_ps(), vfy = _mm256_setzero_ps();
         for (uint32_t j = 0; j < J->n; j++) {
             const __m256 dx = _mm256_sub_ps(_mm256_set1_ps(J->in[4 * j]), vsx), dy = _mm256_sub_ps(_mm256_set1_ps(J->in[4 * j + 1]), vsy);
-            const __m256 d = _mm256_sqrt_ps(_mm256_fmadd_ps(dx, dx, _mm256_mul_ps(dy, dy)));      /* sqrtf(fmaf(dx, dx, dy * dy)) */
-            const __m256 dist = _mm256_blendv_ps(vmin, d, _mm256_cmp_ps(d, vmin, _CMP_GT_OQ));       /* d > 0.001f ? d : 0.001f */
-            const __m256 inv = _mm256_div_ps(one, dist);
-            const __m256 nx = _mm256_fmadd_ps(_mm256_mul_ps(dx, inv), vf, vfx), ny = _mm256_fmadd_ps(_mm256_mul_ps(dy, inv), vf, vfy);
+            const __m256 d2 = _mm256_fmadd_ps(dx, dx, _mm256_mul_ps(dy, dy));                      /* fmaf(dx, dx, dy * dy) */
+            const __m256 d2c = _mm256_blendv_ps(vc, d2, _mm256_cmp_ps(d2, vc, _CMP_GT_OQ));          /* d2 > c ? d2 : c */
+            const __m256 inv = gm_rsqrt8(d2c);
+            const __m256 fs = _mm256_mul_ps(inv, vf);
+            const __m256 nx = _mm256_fmadd_ps(dx, fs, vfx), ny = _mm256_fmadd_ps(dy, fs, vfy);
             const __m256 self = _mm256_castsi256_ps(_mm256_cmpeq_epi32(vid, _mm256_set1_epi32((int)j)));
             vfx = _mm256_blendv_ps(nx, vfx, self);                                                /* j == idx: the pair is skipped */
             vfy = _mm256_blendv_ps(ny, vfy, self);
@@ -985,7 +1015,7 @@ static void gravity_range_const(const grav_job* J, float f)
                 px = gm_fract((px + 1.0f) * 0.5f) * 2.0f - 1.0f;
                 py = gm_fract((py + 1.0f) * 0.5f) * 2.0f - 1.0f;
             }
-            J->out[4 * idx] = px; J->out[4 * idx + 1] = py; J->out[4 * idx + 2] = vx; J->out[4 * idx + 3] = vy;
+            J->out[4 * (idx - J->out_base)] = px; J->out[4 * (idx - J->out_base) + 1] = py; J->out[4 * (idx - J->out_base) + 2] = vx; J->out[4 * (idx - J->out_base) + 3] = vy;
         }
     }
 }
@@ -1035,6 +1065,35 @@ int game_oracle_gravity(const void* blob, size_t blob_len, uint32_t n, float* pa
     return 0;
 }
 
+/* One step for the particles [first, first + count) of an n-particle set, each against all n (what one rank of an
+ * index-sharded run computes, and what lets a few particles of a very large set be checked in O(count * n)).
+ * particles: n x {pos.x, pos.y, vel.x, vel.y} (read only); out: count x 4; time = the dispatch clock of the step. */
+int game_oracle_gravity_range(const void* blob, size_t blob_len, uint32_t n, const float* particles, float dt, float time,
+                              uint32_t first, uint32_t count, float* out, int nthreads)
+{
+    ir_view ir;
+    if (ir_open(blob, blob_len, &ir) != 0 || !ir.h->gravity_present || !particles || !out) return -1;
+    if (count == 0 || (uint64_t)first + count > n) return -1;
+    if (nthreads < 1) nthreads = 1;
+    if ((uint32_t)nthreads > count) nthreads = (int)count;
+    grav_job* jobs = (grav_job*)calloc((size_t)nthreads, sizeof(grav_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+    if (!jobs || !th) { free(jobs); free(th); return -1; }
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t].ir = &ir; jobs[t].in = particles; jobs[t].out = out; jobs[t].n = n; jobs[t].dt = dt; jobs[t].time = time;
+        jobs[t].out_base = first;
+        jobs[t].begin = first + (uint32_t)((uint64_t)count * (uint32_t)t / (uint32_t)nthreads);
+        jobs[t].end = first + (uint32_t)((uint64_t)count * (uint32_t)(t + 1) / (uint32_t)nthreads);
+    }
+    if (nthreads == 1) gravity_thread(&jobs[0]);
+    else {
+        for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, gravity_thread, &jobs[t]);
+        for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    }
+    free(jobs); free(th);
+    return 0;
+}
+
 /* SplitMix64 particle initialisation used by the synthetic particle workloads:
  * pos = (u >> 40) * 2^-23 - 1 per coordinate, vel = 0. */
 void game_oracle_seed_particles(uint32_t n, uint64_t seed, float* particles)
@@ -1067,3 +1126,29 @@ float game_oracle_voronoi2d(float x, float y, float s) { return voronoi2d(x, y, 
 float game_oracle_pow(float x, float y) { return gm_pow(x, y); }
 float game_oracle_exp(float x) { return gm_exp(x); }
 float game_oracle_log(float x) { return gm_log(x); }
+float game_oracle_rsqrt(float x) { return gm_rsqrt(x); }
+void game_oracle_rsqrt_array(uint32_t n, const float* x, float* out) { for (uint32_t i = 0; i < n; i++) out[i] = gm_rsqrt(x[i]); }
+
+/* Self-check of gm_rsqrt_cr against integer arithmetic, over every float of [1, 4) (both exponent parities of
+ * every significand; 1 / sqrt(4^k x) = 2^-k / sqrt(x) exactly, so these stand for all normal inputs). For
+ * x = X / 2^23 (X in [2^23, 2^25)) the result in units of 2^-24 is sqrt(2^71 / X): F = the largest integer with
+ * F^2 X <= 2^71, rounded up when (2F + 1)^2 X < 2^73 - except for the one input the definition excepts,
+ * 4 (1 - 2^-23). Returns the number of inputs where gm_rsqrt_cr differs. */
+uint32_t game_oracle_rsqrt_selfcheck(uint32_t* first_bad)
+{
+    typedef unsigned __int128 u128;
+    uint32_t bad = 0;
+    for (uint32_t X = 1u << 23; X < (1u << 25); X++) {
+        float x = gm_from_bits(X < (1u << 24) ? 0x3f800000u + (X - (1u << 23)) : 0x40000000u + ((X - (1u << 24)) >> 1));
+        if (X >= (1u << 24) && (X & 1u)) continue;                      /* [2, 4): only even X are floats */
+        uint64_t F = (uint64_t)sqrt(0x1p71 / (double)X);
+        while ((u128)F * F * X > ((u128)1 << 71)) F--;
+        while ((u128)(F + 1) * (F + 1) * X <= ((u128)1 << 71)) F++;
+        uint64_t M = 2 * F + 1;
+        uint64_t Y = ((u128)M * M * X < ((u128)1 << 73)) ? F + 1 : F;   /* nearest integer to sqrt(2^71 / X) */
+        if (X == (1u << 25) - 4u) Y = 1u << 23;                         /* the stated exception: 4 (1 - 2^-23) -> 1 / 2 */
+        float want = (float)Y * 0x1p-24f;                                /* Y <= 2^24: exact */
+        if (gm_bits(gm_rsqrt_cr(x)) != gm_bits(want)) { if (!bad && first_bad) *first_bad = gm_bits(x); bad++; }
+    }
+    return bad;
+}

@@ -63,6 +63,34 @@ static inline float gm_smoothstep(float e0, float e1, float x)
 }
 static inline float gm_length2(float x, float y) { return sqrtf(fmaf(x, x, y * y)); }
 
+/* inversesqrt. For 2^-100 <= x < inf the exact 1 / sqrt(x) rounded ONCE to the nearest float - with one stated
+ * exception: for x two floats below a power of four, x = 4^k (1 - 2^-23), the result is 2^-k (the exact value
+ * lies 4.5e-8 ulp above the midpoint of 2^-k and its upper neighbour; an error of 0.50000005 ulp instead of at most
+ * 0.5. A Newton step from any seed equal to 2^-k lands exactly on that midpoint, which is why the definition takes the
+ * even neighbour there). Elsewhere 1 / sqrt(x) as two IEEE operations (0 -> +inf, +inf -> 0, negative -> NaN).
+ * The binary64 quotient 1 / sqrt(x) is within two binary64 ulps of the exact value, so the binary32 at or below it (a)
+ * and the next one (b) bracket the exact value; which of the two is nearer is decided exactly: with m = (a + b) / 2
+ * (25 significant bits, so m * m is exact in binary64) the sign of x * m^2 - 1, one fused operation, says on which
+ * side of m the exact value lies. A tie is impossible (m has an odd 25-bit significand, so x * m^2 is never a power
+ * of two). */
+static inline float gm_rsqrt_cr(float x)
+{
+    if ((gm_bits(x) & 0x00ffffffu) == 0x007ffffeu)   /* 4^k (1 - 2^-23), biased exponent E = 2 k + 126: the result is 2^-k */
+        return gm_from_bits((127u - ((gm_bits(x) >> 23) - 126u) / 2u) << 23);
+    const double xd = (double)x;
+    const double yd = 1.0 / sqrt(xd);
+    float a = (float)yd;
+    if ((double)a > yd) a = gm_from_bits(gm_bits(a) - 1u);   /* the binary32 at or below yd (positive, normal) */
+    const float b = gm_from_bits(gm_bits(a) + 1u);
+    const double m = 0.5 * ((double)a + (double)b);
+    return fma(xd, m * m, -1.0) > 0.0 ? a : b;                /* m above the exact value: the exact value is nearer a */
+}
+static inline float gm_rsqrt(float x)
+{
+    if (x >= 0x1p-100f && x < INFINITY) return gm_rsqrt_cr(x);
+    return 1.0f / sqrtf(x);
+}
+
 /* ── sin / cos ────────────────────────────────────────────────────────────────────────────
  * k = rint(x / pi); r = x - k*pi by three-constant Cody-Waite with fma for |x| <= 32768, by
  * two-constant double-precision reduction up to 2^31; beyond that (float spacing >= 256

@@ -36,6 +36,34 @@ def f(x):
     return np.asarray(x, dtype=np.float32)
 
 
+def rsqrt(x):
+    """inversesqrt as the render path defines it: the exact 1 / sqrt(x) rounded ONCE to float32 for
+    2^-100 <= x < inf (one excepted class of inputs, below), 1 / sqrt(x) as two operations elsewhere. The float64 quotient rounded to float32 is that value
+    unless it sits within a few float64 ulps of the midpoint of two floats; those elements are decided in integers."""
+    x = f(x)
+    # the one stated exception: the float two below a power of four, 4^k (1 - 2^-23), gives 2^-k
+    xb = x.view(np.uint32)
+    excepted = (xb & np.uint32(0x00FFFFFF)) == np.uint32(0x007FFFFE)
+    exc_value = np.ldexp(F(1.0), -((xb >> np.uint32(23)).astype(np.int32) - 126) // 2).astype(np.float32)   # E = 2 k + 126 -> 2^-k
+    with np.errstate(divide="ignore", invalid="ignore"):
+        plain = (F(1.0) / np.sqrt(x)).astype(np.float32)
+        yd = 1.0 / np.sqrt(x.astype(np.float64))
+    out = yd.astype(np.float32)
+    in_range = (x >= F(2.0 ** -100)) & np.isfinite(x)
+    low = yd.view(np.int64) & 0x1FFFFFFF
+    for i in np.flatnonzero((in_range & (np.abs(low - 0x10000000) <= 8)).reshape(-1)):
+        from fractions import Fraction
+        xv = Fraction(float(x.reshape(-1)[i]))
+        a = np.float32(yd.reshape(-1)[i])
+        cands = [np.nextafter(a, F(0)), a, np.nextafter(a, F(np.inf))]
+        # nearest candidate to 1 / sqrt(x): compare squared distances without taking a root: |c - y| smallest, y^2 = 1 / x
+        lo, mid, hi = (Fraction(float(c)) for c in cands)
+        m1, m2 = (lo + mid) / 2, (mid + hi) / 2
+        pick = cands[0] if m1 * m1 * xv > 1 else (cands[1] if m2 * m2 * xv > 1 else cands[2])
+        out.reshape(-1)[i] = pick
+    return np.where(in_range, np.where(excepted, exc_value, out), plain).astype(np.float32)
+
+
 def fma(a, b, c):
     """Correctly rounded float32 a*b+c: the product is exact in float64, the sum is rounded to odd
     (53 >= 2*24+2 bits), and the final float64 -> float32 conversion rounds once."""
@@ -167,8 +195,9 @@ def render_c3_no_grain(w, h, bass, mid, treble):
     lum = r * F(0.299) + g * F(0.587) + b * F(0.114)
     add = np.maximum(lum - F(0.4), F(0.0)) * F(2.0)
     r, g, b = r + add, g + add, b + add
-    ln = np.sqrt(fma(uvx, uvx, uvy * uvy))
-    dirx = quotient(uvx, ln) * F(0.6)
+    d2 = fma(uvx, uvx, uvy * uvy)
+    ln = np.sqrt(d2)
+    dirx = (uvx / ln if LITERAL else uvx * rsqrt(d2)) * F(0.6)     # normalize(uv) = uv * inversesqrt(dot(uv, uv))
     r, b = r * (F(1.0) + dirx), b * (F(1.0) - dirx)
     fac = F(1.0) - smoothstep(0.8, F(0.8) + F(0.35), ln)
     return pack(r * fac, g * fac, b * fac, 1.0)
@@ -183,7 +212,7 @@ def memory_mix(cur_rgba_float, prev_rgba8, decay):
 def gravity_step(p, dt, damping, law, bounds, time):
     """One step of gravity.rs:70-117 on an (n, 4) float32 array {pos.x, pos.y, vel.x, vel.y}: every
     particle sums, in index order, dir * law(dist) over the others with dist = max(length(diff), 0.001),
-    dir = diff * (1 / dist) and an fma per accumulated term; then damped velocity, position, bounds.
+    force += diff * (law * inversesqrt(max(|diff|^2, c))), an fma per component; then damped velocity, position, bounds.
     `law(dist, time)` works on float32 arrays. Vectorised over the receiving particle, sequential in j."""
     p = np.asarray(p, dtype=np.float32)
     n = p.shape[0]
@@ -192,9 +221,15 @@ def gravity_step(p, dt, damping, law, bounds, time):
     idx = np.arange(n)
     for j in range(n):
         dx, dy = p[j, 0] - sx, p[j, 1] - sy
-        dist = np.maximum(np.sqrt(fma(dx, dx, dy * dy)), F(0.001))
+        d2 = fma(dx, dx, dy * dy)
+        dist = np.maximum(np.sqrt(d2), F(0.001))
         f = np.broadcast_to(np.asarray(law(dist, F(time)), dtype=np.float32), dist.shape)
-        nfx, nfy = fma(quotient(dx, dist), f, fx), fma(quotient(dy, dist), f, fy)
+        if LITERAL:
+            nfx, nfy = fma(dx / dist, f, fx), fma(dy / dist, f, fy)
+        else:   # diff * (law * inversesqrt(max(d2, c))); c = the smallest float whose root rounds to 0.001
+            inv = rsqrt(np.where(d2 > F(float.fromhex("0x1.0c6f7ap-20")), d2, F(float.fromhex("0x1.0c6f7ap-20"))))
+            fs = inv * f
+            nfx, nfy = fma(dx, fs, fx), fma(dy, fs, fy)
         keep = idx == j
         fx, fy = np.where(keep, fx, nfx), np.where(keep, fy, nfy)
     vx = p[:, 2] * F(damping) + fx * F(dt)

@@ -263,3 +263,111 @@ def test_gpu_vector_expressions_match_oracle(game, oracle, semantics):
     r.close()
     want = oracle.render_sequence(cin.blob, w, h, rows, False, semantics=semantics, animate=True)
     assert np.array_equal(got, want)
+
+
+# ── ternaries and named colours (expr.rs:132-142 `select(f, t, c)`, expr.rs:13-36 `vec3f(r, g, b)`) ─────────────────
+SEL = '''cinematic "sel" {
+  layer a {
+    fn: rotate(time > 1.0 ? 0.5 : -0.5) | circle(audio.bass > 0.5 ? 0.3 : 0.1 + knob * 0.1) | glow(p.x > 0.0 ? 2.0 : (p.y < 0.0 ? 1.0 : 0.5))
+        | tint(uv.x > 0.0 ? gold : [0.2, 0.3, 0.9])
+    knob: 0.5
+  }
+  layer b { fn: circle(0.2) | shade(mix(ember, frost, audio.mid)) }
+  layer c { fn: ring(0.3, 0.02) | glow(1.5) | tint(gold) }
+  layer d { fn: ring(0.4, 0.02) | glow(1.5) | tint(violet * 0.5 + [0.1, 0.0, 0.2]) }
+}'''
+
+COLOURS = {"black": (0.0, 0.0, 0.0), "white": (1.0, 1.0, 1.0), "red": (1.0, 0.0, 0.0), "green": (0.0, 1.0, 0.0), "blue": (0.0, 0.0, 1.0),
+           "gold": (0.831, 0.686, 0.216), "midnight": (0.039, 0.039, 0.118), "obsidian": (0.071, 0.059, 0.082),
+           "ember": (0.898, 0.318, 0.129), "cyan": (0.0, 1.0, 1.0), "ivory": (1.0, 1.0, 0.941), "frost": (0.686, 0.878, 0.953),
+           "orange": (1.0, 0.647, 0.0), "deep_blue": (0.0, 0.098, 0.392), "ash": (0.467, 0.467, 0.467),
+           "charcoal": (0.212, 0.212, 0.212), "plasma": (0.580, 0.0, 0.827), "violet": (0.541, 0.169, 0.886), "magenta": (1.0, 0.0, 1.0)}
+
+
+def test_ternary_and_colour_arguments_lower_to_programs(game):
+    cin = game.compile(SEL).cinematics[0]
+    ir = cin.ir
+    # frame-level: rotate, circle, shade r/g/b, tint(gold) r/g/b, tint(violet ...) r/g/b; pixel-level: glow, tint(uv.x > 0 ? ...) r/g/b
+    assert cin.derived_count == 2 + 3 + 3 + 3 and cin.pixel_expr_count == 1 + 3
+    assert ir["derived"][0] == "((time > 1.000000) ? 0.500000 : -0.500000)"
+    assert ir["derived"][5:8] == ["gold.r", "gold.g", "gold.b"]
+    assert ir["pixel_exprs"][1] == "((uv.x > 0.000000) ? gold : [0.200000, 0.300000, 0.900000]).r"
+    # what the reference's emitters see stays what the IR resolves: `gold` is a uniform that defaults to 0
+    # (codegen/mod.rs:89-101), the expressions keep the default of `r`, and g / b their own defaults
+    stages = {(li, st["name"]): st for li, layer in enumerate(ir["layers"]) for st in layer["stages"]}
+    gold = stages[(2, "tint")]["args"]
+    assert gold[0]["kind"] == "user" and [a["text"] for a in gold] == ["gold", "1.000000", "1.000000"]
+    assert [a["derived"] for a in gold] == [5, 6, 7]
+    assert [u["name"] for u in ir["uniforms"]] == ["knob", "gold"] and cin.ir["uniforms"][1]["default"] == 0.0
+    # a name the cinematic declares as a parameter is that parameter, not a colour; a colour is no scalar
+    c = game.compile('cinematic "a" { layer x { fn: circle(0.2) | glow(1.0) | tint(gold)\n gold: 0.5 } }').cinematics[0]
+    assert c.derived_count == 0
+    for src in ('circle(gold)', 'glow(ember * 2.0)', 'tint(gold, 0.5)', 'tint([0.1, 0.2])', 'tint(uv ? gold : red)', 'tint(p.x > 0.0 ? gold : uv)'):
+        c = game.compile('cinematic "a" { layer x { fn: circle(0.2) | glow(1.0) | %s } }' % src if not src.startswith(("circle", "glow"))
+                         else 'cinematic "a" { layer x { fn: %s | glow(1.0) } }' % src if src.startswith("circle")
+                         else 'cinematic "a" { layer x { fn: circle(0.2) | %s } }' % src).cinematics[0]
+        assert c.derived_count == 0 and c.pixel_expr_count == 0, src
+
+
+def test_every_named_colour_expands_to_its_components(game):
+    for name, rgb in COLOURS.items():
+        cin = game.compile('cinematic "a" { layer x { fn: circle(0.2) | glow(1.0) | tint(%s) } }' % name).cinematics[0]
+        assert cin.derived_count == 3, name
+        got = cin.eval_derived(cin.uniform_rows([0.0], 8, 8))[0]
+        assert np.array_equal(got, np.array(rgb, dtype=np.float32)), name
+
+
+def test_ternary_values_follow_the_expressions(game):
+    cin = game.compile(SEL).cinematics[0]
+    for t, bass, mid in ((0.5, 0.2, 0.0), (1.5, 0.7, 0.25), (1.0, 0.5, 1.0), (130.0, float("nan"), 0.5)):
+        rows = cin.uniform_rows([t], 16, 9, audio={"bass": bass, "mid": mid}, user={"knob": 0.4})
+        got = cin.eval_derived(rows)[0]
+        tw = wrapped_time(rows[0][0])
+        want = [f32(0.5) if tw > 1.0 else -f32(0.5),
+                f32(0.3) if bass > 0.5 else f32(0.1) + f32(0.4) * f32(0.1)]
+        m = float(rows[0][2])
+        want += [f32(a) * (1.0 - m) + f32(b) * m for a, b in zip(COLOURS["ember"], COLOURS["frost"])]
+        want += [f32(v) for v in COLOURS["gold"]]
+        want += [f32(v) * f32(0.5) + f32(o) for v, o in zip(COLOURS["violet"], (0.1, 0.0, 0.2))]
+        assert np.array_equal(got.view(np.uint32), np.array(want, dtype=np.float64).astype(np.float32).view(np.uint32)), (t, bass, mid)
+
+
+def test_oracle_select_takes_the_branch_per_pixel(game, oracle):
+    from np_restatement import F, pack, pixel_grid
+    src = 'cinematic "a" { layer x { fn: gradient() | tint(uv.x > 0.0 ? gold : [0.2, 0.3, 0.9]) } }'
+    cin = game.compile(src).cinematics[0]
+    w, h = 37, 21
+    got = oracle.render(cin.blob, w, h, cin.uniform_rows([0.0], w, h)[0], animate=True)
+    uvx, uvy = pixel_grid(w, h)
+    t = uvy * F(0.5) + F(0.5)
+    right = uvx > 0
+    r, g, b = (np.where(right, F(a), F(c)) for a, c in zip(COLOURS["gold"], (0.2, 0.3, 0.9)))
+    assert np.array_equal(got, pack(t * r, t * g, t * b, 1.0))
+    # without the flag `gold` is the reference's uniform (0), green and blue keep their defaults
+    still = oracle.render(cin.blob, w, h, cin.uniform_rows([0.0], w, h)[0])
+    assert np.array_equal(still, pack(t * F(1.0), t, t, 1.0))       # an expression argument keeps the default of r (1.0)
+
+
+def test_select_and_colour_kernels_compile_for_gfx950(game):
+    cin = game.compile(SEL).cinematics[0]
+    assert cin.compile_only(animate=True) > 0 and cin.compile_only(semantics="wgsl", animate=True) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("semantics", ["glsl", "wgsl"])
+def test_gpu_ternary_and_colour_arguments_match_oracle(game, oracle, semantics):
+    cin = game.compile(SEL).cinematics[0]
+    w, h = 160, 90
+    rows = cin.uniform_rows([0.25, 1.5, 3.0], w, h, audio={"bass": [0.2, 0.7, 0.5], "mid": [0.0, 0.5, 1.0]}, user={"knob": 0.4})
+    r = cin.renderer(w, h, semantics=semantics, animate=True)
+    got = r.render(rows)
+    assert "gd_select(" in r.kernel_source
+    r.close()
+    want = oracle.render_sequence(cin.blob, w, h, rows, False, semantics=semantics, animate=True, derived=cin.eval_derived(rows))
+    assert np.array_equal(got, want)
+    # without the flag: the reference's substitution (defaults; `gold` = the uniform at 0)
+    r = cin.renderer(w, h, semantics=semantics)
+    got = r.render(rows)
+    r.close()
+    still = oracle.render_sequence(cin.blob, w, h, rows, False, semantics=semantics)
+    assert np.array_equal(got, still) and not np.array_equal(still, want)

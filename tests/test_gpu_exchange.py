@@ -94,3 +94,10 @@ def test_shutdown_releases_tables_and_later_contexts_rebuild_them(game, oracle):
         r.close()
         game.shutdown()
     game.shutdown()                                    # nothing left: still fine
+    # while a context exists the tables stay: its kernels read them through pointers it holds
+    r = cin.renderer(w, h)
+    with pytest.raises(game.GameError, match="still exist"):
+        game.shutdown()
+    assert np.array_equal(r.render(rows)[0], want)
+    r.close()
+    game.shutdown()

@@ -43,7 +43,7 @@ def test_device_present(game):
 
 
 # ── hardware instructions vs their defining formulas, all 2^32 inputs ───────────────────
-@pytest.mark.parametrize("which", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("which", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_exhaustive_instruction_semantics(game, which):
     mismatches, first = game.check_exhaustive(which)
     assert mismatches == 0, hex(first)
@@ -92,6 +92,22 @@ def test_device_division_and_sqrt_are_correctly_rounded(game):
     tiny = (rng.random(1000, dtype=np.float32) * np.float32(1e-38)).astype(np.float32)     # subnormal range
     assert np.array_equal(_bits(game.device_eval("sqrt", tiny)), _bits(np.sqrt(tiny)))
     assert np.array_equal(_bits(game.device_eval("div", tiny, b[:1000])), _bits(tiny / b[:1000]))
+
+
+def test_device_inversesqrt_matches_oracle(game, oracle):
+    """The seven-instruction reciprocal root (one v_rsq_f32, one Newton step with an exact residual) against the
+    oracle's correctly rounded inversesqrt - which test_oracle checks against integer arithmetic - element by element;
+    game_hip_check_exhaustive(5) and (7) cover every input against the same arbitration evaluated on the device."""
+    rng = np.random.default_rng(31)
+    x = np.concatenate([np.exp(rng.uniform(-69.0, 88.0, 400000)).astype(np.float32),
+                        (rng.random(200000, dtype=np.float32) * 8).astype(np.float32),
+                        np.array([2.0 ** -100, 2.0 ** -101, 1e-38, 1e-45, 0.0, -0.0, 1.0, 4.0, 3.4e38, np.inf, -1.0, np.nan,
+                                  float.fromhex("0x1.0c6f7ap-20")], dtype=np.float32)])
+    want = np.empty_like(x)
+    oracle.L.game_oracle_rsqrt_array(x.size, x.ctypes.data, want.ctypes.data)
+    got = game.device_eval("rsqrt", x)
+    same = (_bits(got) == _bits(want)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), (x[~same][:5], got[~same][:5], want[~same][:5])
 
 
 def test_lattice_hash_table_path_equals_arithmetic_path(game):
@@ -539,6 +555,38 @@ def test_gravity_65536_particles_100_steps(game):
     pos, vel = r.particles_read()
     r.close()
     assert np.array_equal(pos, want[:, :2]) and np.array_equal(vel, want[:, 2:])
+
+
+@pytest.mark.timeout(900)
+def test_gravity_16m_particles_sampled_ranges(game, oracle):
+    """The particle workload at its full size, 2^24 particles: a whole step costs 2.8e14 pair evaluations, so parity is
+    checked on index ranges - the step of a few hundred particles against all 2^24 positions on the GPU
+    (game_hip_particles_step with first / count, what one rank of an index-sharded run computes) against the oracle
+    evaluating just those particles against all positions, bit for bit. Every range starts from the state the GPU holds
+    at that moment (the previous ranges' particles have moved), so later ranges also read positions earlier steps
+    wrote. Ranges: the start, one straddling a 2^20 launch boundary, a ragged one, the end."""
+    n = 1 << 24
+    cin = game.compile(C5_GRAVITY).cinematics[0]
+    r = cin.renderer(16, 16)
+    r.particles_seed(n)
+    pos, vel = r.particles_read()
+    state = np.concatenate([pos, vel], axis=1)
+    del pos, vel
+    assert np.array_equal(state[:4096], oracle.seed_particles(4096))
+    t = 0.0
+    for first, count in ((0, 256), ((1 << 20) * 7 - 100, 256), (12345677, 300), (n - 256, 256)):
+        r.particles_step(1 / 60, 1, first=first, count=count)
+        t = np.float32(np.float32(t) + np.float32(1 / 60))
+        want = oracle.gravity_range(cin.blob, state, 1 / 60, float(t), first, count, threads=16)
+        pos, vel = r.particles_read()
+        got = np.concatenate([pos[first:first + count], vel[first:first + count]], axis=1)
+        assert np.array_equal(got, want), (first, count)
+        # outside the range the buffer the step wrote holds what the other buffer held: the state before this step,
+        # except for ranges stepped one call earlier (double buffering) - so only the range itself is taken over
+        state[first:first + count] = got
+        r.particles_init(state[:, :2], state[:, 2:])
+        r.particles_set_time(float(t))
+    r.close()
 
 
 def test_gravity_fast_build_tolerance(game, oracle):

@@ -113,13 +113,21 @@ def test_damaged_blobs_are_refused(game):
         "function arity": put(blob, pix0 + 8, "<IfI", 11, 0.0, 12),       # one-argument call of max
         "frame slot": put(blob, pix0 + 8, "<IfI", 14, 0.0, cin.frame_floats),
         "dist outside a force law": put(blob, pix0 + 8, "<I", 1),
+        # the last operation of the first pixel expression becomes a push: two values are left where one is the result
+        # (the evaluators would disagree on which of them that is)
+        "two values left": put(blob, pix0 + 8 + 16 * (struct.unpack_from("<I", blob, pix0 + 4)[0] - 1), "<IfI", 0, 1.0, 0),
     }
+    assert struct.unpack_from("<I", blob, pix0 + 8 + 16 * (struct.unpack_from("<I", blob, pix0 + 4)[0] - 1))[0] in (3, 4, 5, 6)   # a binary operator
     for what, bad in cases.items():
         with pytest.raises(game.GameError) as ei:
             game.load_blob(bad)
         assert ei.value.code == 80 and "game_ir_from_blob" in str(ei.value), what   # GAME_E_ARGUMENT
     with pytest.raises(game.GameError):
         game.load_blob(b"")
+    # the oracle's own validator refuses the same program
+    from conftest import Oracle
+    with pytest.raises(AssertionError):
+        Oracle().render(cases["two values left"], 8, 8, cin.uniform_rows([0.0], 8, 8)[0])
     # the force law of a gravity block: no frame-row reads, no pixel reads
     g = game.compile(C5_GRAVITY.replace("damping: 0.995,", "damping: 0.995,\n    rule: 1.0 / (dist * dist + 0.01),")).cinematics[0]
     gb = g.blob

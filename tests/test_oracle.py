@@ -271,6 +271,51 @@ def test_gravity_force_laws_and_threads(game, oracle):
     assert np.array_equal(a, g)
 
 
+def test_inversesqrt_is_correctly_rounded(oracle):
+    """gm_rsqrt (the reciprocal root of the gravity step and of normalize(uv)) against integer arithmetic over every
+    float of [1, 4) - all significands at both exponent parities, which stand for every normal input because
+    1 / sqrt(4^k x) = 2^-k / sqrt(x) exactly - and its special values."""
+    import ctypes
+    first = ctypes.c_uint32(0)
+    assert oracle.L.game_oracle_rsqrt_selfcheck(ctypes.byref(first)) == 0, hex(first.value)
+    L = oracle.L
+    assert L.game_oracle_rsqrt(4.0) == 0.5 and L.game_oracle_rsqrt(0.25) == 2.0 and L.game_oracle_rsqrt(2.0 ** -100) == 2.0 ** 50
+    assert L.game_oracle_rsqrt(0.0) == np.inf and L.game_oracle_rsqrt(np.inf) == 0.0 and np.isnan(L.game_oracle_rsqrt(-1.0))
+    # the one excepted class, 4^k (1 - 2^-23) -> 2^-k, at both ends of the range and in the middle
+    for k in (-49, 0, 1, 64):
+        x = np.float32(4.0 ** k if k < 64 else np.inf)
+        x = np.nextafter(np.nextafter(x, np.float32(0)), np.float32(0))
+        assert L.game_oracle_rsqrt(float(x)) == 2.0 ** -k, k
+        from np_restatement import rsqrt as np_rsqrt
+        assert float(np_rsqrt(np.array([x], dtype=np.float32))[0]) == 2.0 ** -k
+    # scaling by powers of four is exact, and the numpy statement of the same definition agrees
+    from np_restatement import rsqrt
+    rng = np.random.default_rng(3)
+    x = (rng.random(20000, dtype=np.float32) * 3 + 1).astype(np.float32)
+    for k in (-40, -7, 0, 9, 50):
+        xs = (x * np.float32(4.0 ** k)).astype(np.float32)
+        got = np.empty_like(xs)
+        L.game_oracle_rsqrt_array(xs.size, xs.ctypes.data, got.ctypes.data)
+        assert np.array_equal(got, rsqrt(xs))
+        base = np.empty_like(x)
+        L.game_oracle_rsqrt_array(x.size, x.ctypes.data, base.ctypes.data)
+        assert np.array_equal(got, (base * np.float32(2.0 ** -k)).astype(np.float32))
+
+
+def test_gravity_range_equals_whole_step(game, oracle):
+    """game_oracle_gravity_range (a few particles against all) returns what the whole-set step gives those particles."""
+    cin = game.compile(C5_GRAVITY).cinematics[0]
+    p = oracle.seed_particles(1500, seed=5)
+    whole, t = oracle.gravity(cin.blob, p, 1 / 60, 1)
+    for first, count in ((0, 1500), (0, 7), (700, 300), (1499, 1)):
+        part = oracle.gravity_range(cin.blob, p, 1 / 60, t, first, count, threads=3)
+        assert np.array_equal(part, whole[first:first + count]), (first, count)
+    law = 'cinematic "t" { gravity { rule: 0.1 / (dist + 0.2) * cos(time), damping: 0.9, bounds: wrap } layer s { circle() | glow() } }'
+    cin = game.compile(law).cinematics[0]
+    whole, t = oracle.gravity(cin.blob, p, 1 / 60, 1, sim_time=0.5)
+    assert np.array_equal(oracle.gravity_range(cin.blob, p, 1 / 60, t, 300, 500), whole[300:800])
+
+
 def test_seed_particles_known_answer(oracle):
     p = oracle.seed_particles(4)
     # SplitMix64 from seed 0x9E3779B97F4A7C15, top 24 bits of each draw mapped to [-1, 1)

@@ -53,3 +53,72 @@ def test_render_into_rejects_what_does_not_fit(game):
     r.sync()
     assert np.array_equal(buf.cpu().numpy().reshape(1, 8, 16, 4), r.render(rows[:1]))
     r.close()
+
+
+def test_two_contexts_alternate_without_a_host_wait(game):
+    """Every context of a GPU stages its uniform rows in the same static array. Two renderers driven back to back from
+    one thread, with no sync in between, must not overwrite each other's rows while a kernel still reads them: each
+    call's refill waits on the device for the previous reader."""
+    import torch
+    a_cin, b_cin = game.compile(C2_FBM).cinematics[0], game.compile(C3_SHOWCASE).cinematics[0]
+    w, h, n = 512, 288, 12
+    ra, rb = a_cin.renderer(w, h), b_cin.renderer(w, h)
+    ref_a, ref_b = a_cin.renderer(w, h), b_cin.renderer(w, h)
+    bufs, wants = [], []
+    for rnd in range(4):
+        ta = [(rnd * n + k) / 24.0 for k in range(n)]
+        rows_a = a_cin.uniform_rows(ta, w, h)
+        rows_b = b_cin.uniform_rows(ta, w, h, audio={"bass": [0.1 + 0.05 * k for k in range(n)], "mid": 0.6, "treble": 0.3})
+        wants += [ref_a.render(rows_a), ref_b.render(rows_b)]
+        bufs += [_dev_buffer(torch, n * h * w * 4), _dev_buffer(torch, n * h * w * 4)]
+    for rnd in range(4):                                   # queue everything, wait once
+        ta = [(rnd * n + k) / 24.0 for k in range(n)]
+        ra.render_into(a_cin.uniform_rows(ta, w, h), bufs[2 * rnd].data_ptr())
+        rb.render_into(b_cin.uniform_rows(ta, w, h, audio={"bass": [0.1 + 0.05 * k for k in range(n)], "mid": 0.6, "treble": 0.3}),
+                       bufs[2 * rnd + 1].data_ptr())
+    ra.sync(); rb.sync()
+    for i, (buf, want) in enumerate(zip(bufs, wants)):
+        assert np.array_equal(buf.cpu().numpy().reshape(n, h, w, 4), want), f"call {i}"
+    for r in (ra, rb, ref_a, ref_b):
+        r.close()
+
+
+def test_render_into_is_refused_while_a_frame_filter_is_set(game):
+    import torch
+    cin = game.compile(C4_TRAILS).cinematics[0]
+    w, h = 128, 72
+    r = cin.renderer(w, h)
+    rows = cin.uniform_rows([0.0, 0.1], w, h, audio={"bass": 0.4})
+    buf = _dev_buffer(torch, 2 * h * w * 4)
+    r.set_blur(2)
+    with pytest.raises(game.GameError, match="frame filter") as ei:
+        r.render_into(rows, buf.data_ptr())
+    assert ei.value.code == 83                              # GAME_E_UNSUPPORTED
+    filtered = r.render(rows)                               # the filtered path itself is untouched by the refusal
+    r.set_blur(0)
+    r.reset_memory()
+    r.render_into(rows, buf.data_ptr())
+    r.sync()
+    plain = buf.cpu().numpy().reshape(2, h, w, 4)
+    ref = cin.renderer(w, h)
+    assert np.array_equal(plain, ref.render(rows)) and not np.array_equal(plain, filtered)
+    ref.close()
+    r.close()
+
+
+def test_render_into_allocates_no_device_memory(game):
+    """Free device memory as the driver reports it before and after a run of calls (the first call included)."""
+    import torch
+    cin = game.compile(C4_TRAILS).cinematics[0]
+    w, h, n = 256, 144, 8
+    r = cin.renderer(w, h)
+    rows = cin.uniform_rows([k / 30.0 for k in range(n)], w, h, audio={"bass": 0.3})
+    buf = _dev_buffer(torch, n * h * w * 4)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(5):
+        r.render_into(rows, buf.data_ptr())
+    r.sync()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0, (free0, free1)
+    r.close()
