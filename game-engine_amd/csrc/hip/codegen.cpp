@@ -250,6 +250,10 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     k += "    gd_u32* __restrict__ dst = P.out + (unsigned long long)slot * P.frame_pixels + (unsigned long long)ty * P.w;\n";
     k += "    GdPix s;\n";
     k += "    s.lut = P.lut; s.vlut = P.vlut; s.slut = P.slut;\n";
+    // Speculating (see GdGuard): the four pixels of a lane run with every range test recorded instead of branched on, then
+    // one test per wave; only when some lane left a range do the four pixels run again with the tests taken.
+    const bool speculate = shape.speculate && nvec == 1;
+    k += std::string("    s.guard.speculate = ") + (speculate ? "true" : "false") + "; s.guard.left_range = false;\n";
     k += "    s.time = U[" + std::to_string(shape.time_slot) + "];\n";
     k += "    const float aspect = U[" + std::to_string(shape.aspect_slot) + "];\n";
     k += "    s.bass = U[1]; s.mid = U[2]; s.treble = U[3];\n";
@@ -259,6 +263,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
         k += "    const float vy = ((float)(P.h - 1u - ty) + 0.5f) * P.inv_h;\n";   // GL row 0 is the bottom row
         k += "    s.uvy = vy * 2.0f - 1.0f;\n";
     }
+    size_t pixel_loop_begin = 0;
     if (nvec > 1) {
         const std::string nv = std::to_string(nvec);
         if (ir.uses_memory) {
@@ -281,6 +286,7 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
             k += "    gd_u32x4 pv = {0u, 0u, 0u, 0u};\n"
                  "    if (P.prev) pv = " + ld4 + "(P.prev + (unsigned long long)ty * P.w + x0));\n";
         k += "    gd_u32x4 q;\n";
+        pixel_loop_begin = k.size();
         k += "#pragma unroll\n    for (gd_u32 kx = 0; kx < 4u; ++kx) {\n    const gd_u32 x = x0 + kx;\n";
         k += "    {\n";
         if (ir.uses_memory) k += "    const gd_u32 prev = pv[kx];\n";
@@ -388,6 +394,14 @@ std::string generate_frame_kernel(const Ir& ir, const KernelShape& shape)
     } else if (nvec == 1) {
         k += "    q[kx] = gd_pack_rgba8(fr, fg, fb, fa);\n";
         k += "    }\n    }\n";
+        if (speculate) {
+            const std::string loop = k.substr(pixel_loop_begin);
+            k += "    if (__builtin_expect(__builtin_amdgcn_ballot_w64(s.guard.left_range) != 0ull, 0)) {   // rare: some lane left a fast range\n";
+            k += "    s.guard.speculate = false;\n";
+            k += loop;
+            k += "    s.guard.speculate = true; s.guard.left_range = false;\n";
+            k += "    }\n";
+        }
         k += "    *(gd_u32x4*)(dst + x0) = q;\n";
     } else {
         k += "    dst[x] = gd_pack_rgba8(fr, fg, fb, fa);\n";

@@ -18,6 +18,8 @@ struct KernelShape {
     uint32_t wg = 256;              // threads per workgroup (a multiple of 64)
     bool stream_prev = false;       // the previous frame is read with a non-temporal hint (frames too large to stay in cache)
     bool row_shared = true;         // with several rows per lane: per-row values worked out once per workgroup, in shared memory
+    bool speculate = false;         // four-pixel lanes: range tests recorded instead of branched on, one check per wave and row
+                                    // (and a second, fully tested evaluation when some lane left a range)
 };
 
 std::string float_literal(float v);

@@ -138,12 +138,13 @@ std::unordered_map<std::string, std::vector<char>> g_code_cache;
 
 int compile_hip_uncached(const std::string& src, const char* name, const std::vector<std::string>& flags, std::vector<char>& code);
 
-int compile_hip(const std::string& src, const char* name, std::vector<char>& code)
+int compile_hip(const std::string& src, const char* name, std::vector<char>& code, const std::vector<std::string>& extra = {})
 {
     // One rounding per source operator: contraction off; fma only where the source says fma.
     // No SLP vectorisation: packed FP32 (v_pk_*_f32) issues at half rate on gfx950, so pairing two
     // scalar operations into one packed instruction only adds the moves that build the pairs.
     std::vector<std::string> flags = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
+    flags.insert(flags.end(), extra.begin(), extra.end());
     // Tuning hook: extra hiprtc options, space separated (later options override earlier ones).
     if (const char* extra = getenv("GAME_HIP_FLAGS")) {
         std::string e(extra);
@@ -261,10 +262,17 @@ KernelShape shape_for(const Ir& ir, uint32_t width, uint32_t height, uint32_t fl
     // plain load is as fast or faster (the previous frame is still cached when it is read).
     s.stream_prev = ir.uses_memory && (unsigned long long)width * height * 8ull > 200000000ull;
     if (const char* e = getenv("GAME_HIP_NTLOAD")) s.stream_prev = atoi(e) != 0;   // tuning hook
+    // Four-pixel lanes run a little faster in one-wave workgroups (a row of 3840 pixels is 15 of them instead of 3.75
+    // four-wave ones: c3 +1.7 %, c4 +3 %, c1 unchanged in alternating bench runs on one box).
+    if (s.pixels_per_lane == 4u) s.wg = 64u;
     if (const char* e = getenv("GAME_HIP_WG")) {    // tuning hook
         int v = atoi(e);
         if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) s.wg = (uint32_t)v;
     }
+    // Four-pixel lanes (no noise stage) speculate on their range tests: one check per wave and row instead of a branch per
+    // test, which lets the four pixels' arithmetic overlap (c3 -10 %, c1 -4 % with the scheduler chosen for such kernels).
+    s.speculate = s.pixels_per_lane == 4u;
+    if (const char* e = getenv("GAME_HIP_SPECULATE")) s.speculate = atoi(e) != 0 && s.pixels_per_lane == 4u;   // tuning hook
     uint32_t row = BU_COUNT + (uint32_t)ir.uniforms.size();
     s.time_slot = row;
     s.aspect_slot = row + 1;
@@ -273,6 +281,16 @@ KernelShape shape_for(const Ir& ir, uint32_t width, uint32_t height, uint32_t fl
     s.lens_post = (flags & GAME_HIP_LENS_POST) != 0;
     s.project = (flags & GAME_HIP_PROJECT) != 0;
     return s;
+}
+
+// Compiler options that go with a kernel shape. A speculating kernel is one long basic block per row (four independent
+// pixel chains); the default scheduler (tuned for occupancy) groups the slow instructions of the four pixels together and
+// the block then runs a third slower than the branchy form, while the ILP scheduler interleaves the chains: c3 0.37 ms
+// per 25 frames with the default, 0.244 ms with max-ilp, 0.27 ms for the branchy kernel.
+std::vector<std::string> shape_flags(const KernelShape& s)
+{
+    if (s.speculate) return {"-mllvm", "-amdgpu-sched-strategy=max-ilp"};
+    return {};
 }
 
 // fract as the kernels define it: x - floor(x), kept below 1.
@@ -491,8 +509,9 @@ int game_hip_compile_only_ex(const game_ir* ir, uint32_t flags, size_t* code_byt
 {
     if (!ir) return set_error(GAME_E_ARGUMENT, "game_hip_compile_only: null ir");
     std::vector<char> code;
-    std::string src = generate_frame_kernel(*ir->ir, shape_for(*ir->ir, 3840u, 2160u, flags));
-    int rc = compile_hip(src, "game_frame.hip", code);
+    const KernelShape shape = shape_for(*ir->ir, 3840u, 2160u, flags);
+    std::string src = generate_frame_kernel(*ir->ir, shape);
+    int rc = compile_hip(src, "game_frame.hip", code, shape_flags(shape));
     if (rc) return rc;
     size_t total = code.size();
     if (ir->ir->gravity.present) {
@@ -515,8 +534,9 @@ int game_hip_dump_code(const game_ir* ir, const char* path_prefix)
         return ok;
     };
     std::vector<char> code;
-    std::string src = generate_frame_kernel(*ir->ir, shape_for(*ir->ir, 3840u, 2160u));
-    int rc = compile_hip(src, "game_frame.hip", code);
+    const KernelShape shape = shape_for(*ir->ir, 3840u, 2160u);
+    std::string src = generate_frame_kernel(*ir->ir, shape);
+    int rc = compile_hip(src, "game_frame.hip", code, shape_flags(shape));
     if (rc) return rc;
     std::string pre(path_prefix);
     if (!write(pre + "_frame.hip", src.data(), src.size()) || !write(pre + "_frame.co", code.data(), code.size()))
@@ -563,7 +583,7 @@ int game_hip_create_ex(const game_ir* ir, uint32_t width, uint32_t height, int d
     c->source = generate_frame_kernel(c->ir, c->shape);
     std::vector<char> code;
     double t0 = now_ms();
-    int rc = compile_hip(c->source, "game_frame.hip", code);
+    int rc = compile_hip(c->source, "game_frame.hip", code, shape_flags(c->shape));
     c->compile_ms = (float)(now_ms() - t0);
     if (rc) { game_hip_destroy(c); return rc; }
     auto fail = [&](const char* what, hipError_t err) { int r = hip_fail(what, err); game_hip_destroy(c); return r; };

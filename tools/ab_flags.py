@@ -11,7 +11,7 @@ import conftest as T
 g = T.load_product()
 key = sys.argv[1]
 variants = sys.argv[2:] or [""]
-HOOKS = ("PPL=", "RPL=", "ROWLDS=", "WG=", "NTLOAD=")     # GAME_HIP_<name> shape hooks of the runtime
+HOOKS = ("PPL=", "RPL=", "ROWLDS=", "WG=", "NTLOAD=", "SPECULATE=")     # GAME_HIP_<name> shape hooks of the runtime
 cfg = g.workloads.CONFIGS[key]
 cin = g.compile(cfg["src"]).cinematics[0]
 w, h, batch = cfg["w"], cfg["h"], 25

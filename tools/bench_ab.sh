@@ -1,0 +1,11 @@
+#!/bin/bash
+# Alternating bench.py runs of one config under several environment settings, on one box.
+# usage: tools/bench_ab.sh <config> <rounds> "VAR=val VAR2=val" "..." ...     ("-" = default environment)
+cfg=$1; rounds=$2; shift 2
+for r in $(seq $rounds); do
+  for v in "$@"; do
+    if [ "$v" = "-" ]; then envs=""; else envs="$v"; fi
+    line=$(env $envs timeout -k 10 120 python bench.py --config $cfg --steps 20 --warmup 3 --no-cpu --no-others 2>/dev/null | tail -1)
+    echo "$cfg [$v] $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["roofline"]["avg_launch_ms"])')"
+  done
+done
