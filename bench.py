@@ -13,7 +13,15 @@ a launcher (torch.distributed.run) already did. Rank 0 prints one JSON line.
 
 Other configs (c1, c2b, c3, c4, c5) exercise the remaining benchmark cinematics; c4 shards horizontal bands, c5 shards
 particle indices with an all-gather of positions per step. At N = 1 the default run also times each of them briefly
-after the headline and reports them under "other_configs".
+after the headline and reports them under "other_configs" (among them one step of the particle workload at its full
+size, 2^24 particles: about 80 s).
+
+    --scaling strong   stateless configs: the config's own job (c2: 1000 frames) is split k mod N over the GPUs instead
+                       of every GPU rendering a whole job; value = job pixels / wall time
+    --blur R           c4 with the frame filter on: per frame every rank renders its raw band, trades R raw rows with the
+                       ranks above and below (RCCL point-to-point, device to device), then filters its band
+A config whose data path needs RCCL (c5, c4 with --blur) exits non-zero when RCCL cannot start; only the rehearsal mode
+(GAME_BENCH_REHEARSE=1: all ranks on one GPU, gloo) runs it over host memory, and says so in the line.
 """
 import argparse
 import glob
@@ -100,7 +108,9 @@ def spawn_ranks(n, argv):
     return worst
 
 
-def dist_setup(n_gpus):
+def dist_setup(n_gpus, needs_rccl=False):
+    """needs_rccl: the config's data path runs collectives between the GPUs (particle positions, halo rows); a gloo
+    fallback would carry them through host memory and still print a value, so RCCL failing is an error there."""
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,6 +136,9 @@ def dist_setup(n_gpus):
                     raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
             except Exception as e:              # RCCL unusable on this node: the frame-sharded configs need only a
                 global CONTROL_BACKEND          # barrier and a max over ranks, which gloo provides as well
+                if needs_rccl:
+                    raise SystemExit(f"rank {rank}: RCCL start-up failed ({type(e).__name__}: {e}) and this config exchanges data between "
+                                     "the GPUs: no measurement (GAME_BENCH_REHEARSE=1 rehearses the control flow over gloo)")
                 print(f"rank {rank}: RCCL start-up failed ({type(e).__name__}: {e}); control collectives over gloo", file=sys.stderr, flush=True)
                 if dist.is_initialized():
                     dist.destroy_process_group()
@@ -185,7 +198,18 @@ def valu_roofline(pmc, sec, algorithmic_flops):
         frac = insts * 2.0 / (SIMDS * CLOCK_HZ * sec)
         out.update({"achieved": round(insts * 128.0 / sec / 1e12, 2), "frac": round(frac, 4),
                     "traffic": round(pmc["traffic_bytes_per_launch"]), "valu_instructions_per_launch": round(insts),
-                    "valu_instructions_per_wave": round(pmc["valu_instructions_per_wave"], 1), "counters_from": pmc["file"]})
+                    "valu_instructions_per_wave": round(pmc["valu_instructions_per_wave"], 1), "counters_from": pmc["file"],
+                    "counters_note": "PMC counters come from separate rocprofv3 runs on another box, matched to this kernel build by hash; "
+                                     "the launch time is this run's"})
+        # what the hardware counted as FP32 operations (an fma = 2, a move or a compare = 0), over the vector peak
+        if pmc.get("hw_counted_flops_per_wave_lane"):
+            flops = pmc["hw_counted_flops_per_wave_lane"] * pmc["waves_per_launch"] * 64.0
+            out["executed_tflops"] = round(flops / sec / 1e12, 2)
+            out["frac_executed_flops"] = round(flops / sec / 1e12 / PEAK_FP32_TFLOPS, 4)
+        # the same issue-slot share with the cycle count taken from the counters too (GRBM_GUI_ACTIVE, summed over the
+        # 8 XCDs by the profiler) instead of launch time x an assumed 2.4 GHz: no clock assumption, both from the profiled run
+        if pmc.get("gui_active_cycles_per_launch"):
+            out["frac_issue_counted_cycles"] = round(insts * 2.0 / (SIMDS * pmc["gui_active_cycles_per_launch"] / 8.0), 4)
     else:
         out["note"] = "no committed PMC record matches this kernel build and launch shape: frac and traffic not available"
     return out
@@ -198,27 +222,43 @@ def time_frames(args, game, torch, rank, world, local, key, steps, warmup, extra
     cin = game.compile(cfg["src"]).cinematics[0]
     w, h = cfg["w"], cfg["h"]
     banded = cin.uses_memory
-    frames = args.frames if args.frames else cfg["frames"]          # frames per step on this GPU
-    batch = min(args.batch if args.batch else cfg["batch"], frames)  # frames per launch (stateless cinematics)
+    blur = args.blur if banded else 0
+    strong = args.scaling == "strong" and not banded
+    frames = args.frames if args.frames else cfg["frames"]          # frames per step: on this GPU (weak), of the whole job (strong)
     if banded:
         # horizontal bands, multiples of 8 rows; every rank renders every frame of its band. The
-        # feedback read is the same pixel of the previous frame, so no halo rows are exchanged.
+        # feedback read is the same pixel of the previous frame, so no halo rows are exchanged (unless --blur).
         row0, nrows = game.distributed.band_for_rank(h, rank, world)
         ks = list(range(frames))
+    elif strong:
+        row0, nrows = 0, h
+        ks = game.distributed.frames_for_rank(frames, rank, world)   # the job's frame k -> GPU k mod N
     else:
         row0, nrows = 0, h
-        ks = [i * world + rank for i in range(frames)]               # frame k -> GPU k mod N
+        ks = [i * world + rank for i in range(frames)]               # frame k -> GPU k mod N of an N x frames job
+    batch = max(1, min(args.batch if args.batch else cfg["batch"], len(ks)))   # frames per launch (stateless cinematics)
     t_create = time.perf_counter()
     r = cin.renderer(w, h, device=local)
     create_ms = (time.perf_counter() - t_create) * 1e3
     compile_ms, tables_ms = r.setup_ms()
     r.set_ring(2 if banded else batch)
     table = W.frame_rows(cin, key, ks, w, h)
+    halo = None
+    if blur:
+        r.set_blur(blur)
+        if world > 1:
+            halo = game.distributed.BandHaloExchange(r, row0, nrows, blur, torch)
 
     def step():
-        if banded:
+        if blur and world > 1:
+            # two-phase frames: raw band, `blur` raw rows traded with the ranks above and below on the render stream, filter
+            for k in range(len(ks)):
+                r.render_raw_band(table[k], row0, nrows)
+                halo.exchange()
+                r.blur_band(row0, nrows, readback=False)
+        elif banded:
             r.render_band(table, row0, nrows, readback=False)
-        else:
+        elif len(ks):
             r.render(table, readback=False)
 
     for _ in range(warmup):
@@ -237,41 +277,61 @@ def time_frames(args, game, torch, rank, world, local, key, steps, warmup, extra
     if args.events:
         kernel_ms, launches = r.timing_end()
 
-    frames_total = steps * frames * (1 if banded else world)
-    value = frames_total * w * h / dt / 1e6
+    job_frames = frames if (banded or strong) else frames * world     # frames of the whole job, per step
+    value = steps * job_frames * w * h / dt / 1e6
     out = {
         "metric": "Mpixel/s at 3840x2160 (fbm showcase)" if key == "c2" else f"Mpixel/s ({key})",
         "value": round(value, 1), "unit": "Mpixel/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-        "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if banded else "weak",
+        "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if (banded or strong) else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": cfg["workload"], "frames_per_step": frames, "frames_per_launch": 1 if banded else batch,
-                   "job_frames_per_step": frames * (1 if banded else world), "width": w, "height": h,
-                   "parallelism": f"bands{world}" if banded else f"frames{world}", "output": "RGBA8 frames in an HBM ring"},
+        "config": {"workload": cfg["workload"] + (f", every frame blurred (binomial, radius {blur}) before it is stored and fed back" if blur else ""),
+                   "frames_per_step": len(ks), "frames_per_launch": 1 if banded else batch,
+                   "job_frames_per_step": job_frames, "width": w, "height": h,
+                   "parallelism": (f"bands{world}" + (f"+halo{blur}" if blur else "")) if banded else f"frames{world}",
+                   "output": "RGBA8 frames in an HBM ring"},
         "timed_region_s": round(dt, 4),
     }
-    if rank == 0 and args.events and launches:
+    if rank == 0 and args.events and launches and not blur:
         per_launch_frames = 1 if banded else batch
         px_launch = (nrows if banded else h) * w * per_launch_frames
         sec = kernel_ms / launches / 1e3
         # the counters describe one launch of this kernel build; a band launch (N > 1, memory cinematics) is another shape
         pmc = measured_counters(key, per_launch_frames, r.kernel_hash) if (world == 1 or not banded) else None
+        ach = px_launch * cfg["bytes_px"] / sec / 1e9
         if cfg["bound"] == "valu":
             roof = valu_roofline(pmc, sec, px_launch * cfg["flops_px"])
             roof["flops_per_pixel"] = cfg["flops_px"]
+            if not cfg.get("tables"):
+                # no lattice tables: every operator of the flop convention is executed, so the convention's rate over the
+                # vector peak is the fraction; the issue-slot share and the store rate against HBM ride along
+                roof["valu_issue_frac"] = roof["frac"]
+                roof.update({"achieved": roof["algorithmic_tflops"], "frac": roof["algorithmic_over_peak"],
+                             "frac_definition": f"{cfg['flops_px']} flop per pixel (operators of the emitted GLSL) over the FP32 vector peak"})
+            roof.update({"hbm_gbs": round(ach, 1), "hbm_frac": round(ach / PEAK_HBM_GBS, 4), "bytes_per_pixel": cfg["bytes_px"]})
         else:
-            ach = px_launch * cfg["bytes_px"] / sec / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
                     "traffic": round(pmc["traffic_bytes_per_launch"]) if pmc else None, "bytes_per_pixel": cfg["bytes_px"]}
             if pmc:
                 insts = pmc["waves_per_launch"] * pmc["valu_instructions_per_wave"]
                 roof["valu_issue_frac"] = round(insts * 2.0 / (SIMDS * CLOCK_HZ * sec), 4)
-                roof["valu_instructions_per_pixel"] = round(insts * 64.0 / px_launch, 1)
+        if pmc:
+            roof["valu_instructions_per_pixel"] = round(pmc["waves_per_launch"] * pmc["valu_instructions_per_wave"] * 64.0 / px_launch, 1)
+            if pmc.get("salu_instructions_per_wave") is not None:
+                roof["salu_instructions_per_pixel"] = round(pmc["waves_per_launch"] * pmc["salu_instructions_per_wave"] * 64.0 / px_launch, 1)
         roof.update({"kernel": "game_frame", "kernel_hash": r.kernel_hash, "avg_launch_ms": round(sec * 1e3, 4),
                      "pixels_per_launch": px_launch, "launches_timed": launches})
         out["roofline"] = roof
+    if rank == 0 and blur:
+        # both kernels of a frame inside the wall-clock span: 16 B per pixel (raw band written and read back, previous
+        # frame read, filtered frame written)
+        gbs = steps * frames * w * h * 16 / dt / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS * world, "unit": "GB/s",
+                           "frac": round(gbs / (PEAK_HBM_GBS * world), 4), "traffic": None, "bytes_per_pixel": 16,
+                           "kernel": "game_frame + blur_kernel" + (" + halo rows over RCCL" if world > 1 else ""),
+                           "note": "from the wall clock of the timed region (the two-phase band calls carry no event pairs)"}
         out["setup"] = {"context_create_ms": round(create_ms, 1), "kernel_compile_ms": round(compile_ms, 1), "table_build_ms": round(tables_ms, 1)}
-    if rank == 0 and world == 1 and extras and not args.no_cpu:   # comparison legs (skipped together: profiler runs)
-        if cfg["bound"] == "valu" and not os.environ.get("GAME_HIP_NO_LUT") and "roofline" in out:
+    if rank == 0 and world == 1 and extras and not args.no_cpu and not blur:   # comparison legs (skipped together: profiler runs)
+        if cfg.get("tables") and not os.environ.get("GAME_HIP_NO_LUT") and "roofline" in out:
             # the same workload with every hash evaluated arithmetically (no tables), a few launches, outside the main timing
             os.environ["GAME_HIP_NO_LUT"] = "1"
             r2 = cin.renderer(w, h, device=local)
@@ -439,14 +499,20 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="frames per step on each GPU; default = the whole job of the config (c2: 1000)")
     ap.add_argument("--batch", type=int, default=0, help="frames per launch; default 25 (200 for the 1024x1024 config)")
     ap.add_argument("--particles", type=int, default=1048576)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="stateless configs at N > 1: weak = every GPU renders a whole job (N x frames in all), strong = one job split k mod N")
+    ap.add_argument("--blur", type=int, default=0, help="c4 only: frame filter radius 1..4; at N > 1 the bands trade halo rows over RCCL")
     ap.add_argument("--no-events", dest="events", action="store_false", help="skip per-step HIP event timing")
     ap.add_argument("--no-cpu", action="store_true", help="skip the comparison legs (CPU baseline, table-free build, host delivery)")
     ap.add_argument("--no-others", action="store_true", help="skip the brief runs of the other configs after the headline")
+    ap.add_argument("--no-16m", action="store_true", help="skip the 2^24-particle step (about 80 s) among the other configs")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
-    torch, rank, world, local = dist_setup(args.gpus)
+    if args.blur and args.config != "c4":
+        raise SystemExit("--blur applies to --config c4 (the feedback cinematic)")
+    torch, rank, world, local = dist_setup(args.gpus, needs_rccl=args.config == "c5" or (args.config == "c4" and args.blur > 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local)
@@ -462,6 +528,9 @@ def main():
         others["c5"] = brief(time_particles(args, game, torch, rank, world, local, 1048576, 3, 1, False))
         others["c5_fast"] = brief(time_particles(args, game, torch, rank, world, local, 1048576, 3, 1, False, fast=True))
         others["c4_blur4"] = time_filtered_feedback(game, local, 4, 100)
+        if not args.no_16m:
+            # the particle workload at its full size: one step of 2^24 particles (2.8e14 pair evaluations, about 80 s), no warm-up step
+            others["c5_16m"] = brief(time_particles(args, game, torch, rank, world, local, 1 << 24, 1, 0, False))
         out["other_configs"] = others
     if rank == 0:
         if world > 1:

@@ -180,6 +180,11 @@ GD void gd_sincos_poly(float r, gd_u32 sign, float& s_out, float& c_out)
     float s = __builtin_fmaf(ps * z, r, r);
     float pc = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-0x1.184e1ap-22f, z, 0x1.9f7afap-16f), z, -0x1.6c1410p-10f), z, 0x1.55554ep-5f);
     float c = __builtin_fmaf(pc * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+#ifdef GD_SIN_NUDGE   // measurement only: sine and cosine off by GD_SIN_NUDGE units in the last place (away from zero if positive),
+                      // as another correct implementation of the GLSL functions might return them
+    s = gd_from_bits(gd_bits(s) + (gd_u32)(GD_SIN_NUDGE));
+    c = gd_from_bits(gd_bits(c) + (gd_u32)(GD_SIN_NUDGE));
+#endif
     s_out = gd_from_bits(gd_bits(s) ^ sign);
     c_out = gd_from_bits(gd_bits(c) ^ sign);
 }

@@ -28,6 +28,10 @@ for c in configs:
               "valu_instructions_per_wave": k["SQ_INSTS_VALU"]["avg"] / k["SQ_WAVES"]["avg"],
               "valu2_share": k["SQ_ACTIVE_INST_VALU2"]["avg"] / k["SQ_ACTIVE_INST_VALU"]["avg"],
               "hw_counted_flops_per_wave_lane": k["SQ_INSTS_VALU_FLOPS_FP32"]["avg"] / k["SQ_WAVES"]["avg"],
+              "salu_instructions_per_wave": k["SQ_INSTS_SALU"]["avg"] / k["SQ_WAVES"]["avg"],
+              "wait_inst_any_share": k["SQ_WAIT_INST_ANY"]["avg"] / k["SQ_WAVE_CYCLES"]["avg"],
+              # GRBM_GUI_ACTIVE as the profiler reports it: summed over the 8 XCDs, for the launch of the counter pass
+              "gui_active_cycles_per_launch": k.get("GRBM_GUI_ACTIVE", {}).get("avg"),
               "kernel_avg_us_rocprof": res["avg_us"], "vgpr": res["vgpr"], "lds": res["lds"],
               "source": f"profiles/{rnd}_{c}.json (tools/profile_bench.sh: rocprofv3 --kernel-trace --stats, then one --pmc run per counter group)"}
 json.dump(out, open(f"profiles/{rnd}_traffic.json", "w"), indent=1)
