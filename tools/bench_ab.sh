@@ -6,6 +6,6 @@ for r in $(seq $rounds); do
   for v in "$@"; do
     if [ "$v" = "-" ]; then envs=""; else envs="$v"; fi
     line=$(env $envs timeout -k 10 120 python bench.py --config $cfg --steps 20 --warmup 3 --no-cpu --no-others 2>/dev/null | tail -1)
-    echo "$cfg [$v] $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["roofline"]["avg_launch_ms"])')"
+    echo "$cfg [$v] $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); r=d["roofline"]; print(d["value"], r.get("avg_launch_ms", r.get("avg_step_ms")))')"
   done
 done

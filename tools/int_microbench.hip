@@ -35,6 +35,14 @@ __global__ __launch_bounds__(256) void bench(unsigned* out, int iters, unsigned 
             else if constexpr (P == 17) asm volatile(OP3("v_dot2_u32_u16") ::: CLOB);
             else if constexpr (P == 18) asm volatile(OP3("v_mad_u16") ::: CLOB);
             else if constexpr (P == 19) asm volatile(OP3("v_sad_u8") ::: CLOB);
+            else if constexpr (P == 20) asm volatile(OP2("v_max_f32") ::: CLOB);
+            else if constexpr (P == 21) asm volatile(OP2("v_max_u32") ::: CLOB);
+            else if constexpr (P == 22) asm volatile(OP2("v_min_i32") ::: CLOB);
+            else if constexpr (P == 23) asm volatile(OP2("v_mul_f32") ::: CLOB);
+            else if constexpr (P == 24) asm volatile(OP2("v_add_f32") ::: CLOB);
+            else if constexpr (P == 25) asm volatile(OP2("v_xor_b32") ::: CLOB);
+            else if constexpr (P == 26) asm volatile(OP2("v_lshlrev_b32") ::: CLOB);
+            else if constexpr (P == 27) asm volatile(OP2("v_sub_u32") ::: CLOB);
         }
     }
     asm volatile("v_add_u32 %0, %0, v16\n v_add_u32 %0, %0, v23\n" : "+v"(acc) :: CLOB);
@@ -63,6 +71,8 @@ int main()
         run<8>("v_perm_b32", out, wps); run<9>("v_dot4_u32_u8", out, wps); run<10>("v_pk_mad_u16", out, wps); run<11>("v_pk_add_u16", out, wps);
         run<12>("v_lshrrev_b32", out, wps); run<13>("v_lshl_or_b32", out, wps); run<14>("v_alignbyte_b32", out, wps); run<15>("v_bfe_u32", out, wps);
         run<16>("v_and_or_b32", out, wps); run<17>("v_dot2_u32_u16", out, wps); run<18>("v_mad_u16", out, wps); run<19>("v_sad_u8", out, wps);
+        run<20>("v_max_f32", out, wps); run<21>("v_max_u32", out, wps); run<22>("v_min_i32", out, wps); run<23>("v_mul_f32", out, wps);
+        run<24>("v_add_f32", out, wps); run<25>("v_xor_b32", out, wps); run<26>("v_lshlrev_b32", out, wps); run<27>("v_sub_u32", out, wps);
     }
     return 0;
 }
