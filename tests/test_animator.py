@@ -219,3 +219,24 @@ def test_gpu_animated_uniforms_drive_the_frames(game, oracle):
     want = oracle.render_sequence(cin.blob, w, h, rows, False)
     assert np.array_equal(got, want)
     assert not np.array_equal(got[0], got[5])
+
+
+def test_round_and_mod_follow_the_wording_of_their_side(game):
+    """The same expression language has two wordings in the reference: stage arguments are shader expressions
+    (codegen/expr.rs:50-144, WGSL: round() goes to the nearest even integer on a tie), modulations are JavaScript
+    (expr.rs:147-260: Math.round = floor(x + 0.5)). `%` is the exact truncated remainder in both."""
+    src = '''cinematic "r" { layer a { fn: circle(round(time * 2.5) * 0.1) | glow(mod(0.0 - time * 7.5, 2.0) + 2.0)
+      x: 0.0 ~ round(time * 2.5)
+      y: 0.0 ~ mod(0.0 - time * 7.5, 2.0) } }'''
+    cin = game.compile(src).cinematics[0]
+    assert cin.derived_count == 2
+    rows = cin.uniform_rows([1.0, 0.6], 16, 9)
+    d = cin.eval_derived(rows)
+    assert d[0, 0] == np.float32(2.0 * float(np.float32(0.1)))        # round(2.5) = 2: ties to even
+    assert d[1, 0] == np.float32(2.0 * float(np.float32(0.1)))        # round(1.5) = 2
+    assert d[0, 1] == np.float32(-1.5 + 2.0) and d[1, 1] == np.float32(math.fmod(0.0 - float(np.float32(0.6)) * 7.5, 2.0) + 2.0)
+    an = cin.animator(60.0)
+    an.apply(rows, [1.0, 0.6], what=an.MODULATION)
+    an.close()
+    assert rows[0, BU] == 3.0 and rows[1, BU] == 2.0                   # Math.round(2.5) = 3, Math.round(1.5) = 2
+    assert rows[0, BU + 1] == np.float32(-1.5)
