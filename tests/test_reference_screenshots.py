@@ -1,0 +1,107 @@
+"""The only pixels in the reference tree that its own emitted shaders produced: two dev-server screenshots
+(screenshots/01-load.png: presets/dashboard-gauge.game; screenshots/arc-01-load.png: "layered-scene" in the first,
+un-animated moment of its arc timeline, glow_i = 0.5 and orb_glow = 1.0 as the panel shows). A browser rendered them
+from the shader text of an OLDER generation of the compiler, kept in dist/dashboard-gauge.js and dist/layered-scene.js:
+same vertex stage, uv, aspect and `p` as game-compiler/src/codegen/glsl.rs:53-61,:240 and the same ring / circle
+distance functions (glsl.rs:96-100,:269-273), but glow = exp(-max(d, 0) * intensity * 8), additive layer compositing
+and resolved colour names - so they are not vectors for today's `glow` or screen blend.
+
+What they can pin is everything around the builtins: pixel centres, the uv / aspect / p convention at three aspect
+ratios, length / abs / max / exp / mix of the expression evaluator, and the RGBA8 store - on a GPU that is not ours.
+The two cinematics below restate that older shader text with this build's expression-valued arguments (an opt-in
+extension, GAME_HIP_ANIMATE_ARGS): `circle(10.0) | shade(r, g, b)` stores exactly (r, g, b). The crops are committed
+as data (tests/golden/make_reference_screenshot_crops.py); the dev server's two text overlays on the preview pane are
+masked. Bar: every channel within one level of the browser's pixel, at least 95 % of them equal (exp and the final
+rounding are the browser's own)."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+RING = "exp(0.0 - max(abs(length(p) - 0.35) - {t}, 0.0) * {i} * 8.0)"
+DOT = "exp(0.0 - max(length(p) - {r}, 0.0) * {i} * 8.0)"
+
+# dist/dashboard-gauge.js: track ring(0.35, 0.025) glow 0.8 tint (0.85, 0.92, 1.0); fill arc masked away at fill = 0
+# (mask_arc -> 999 -> exp underflows to 0); centre circle(0.04) glow 1.5 tint white; layers added.
+_G_RING, _G_DOT = RING.format(t="0.025", i="0.8"), DOT.format(r="0.04", i="1.5")
+GAUGE = f'''cinematic "gauge-as-rendered" {{
+  layer {{
+    fn: circle(10.0) | shade(0.85 * {_G_RING} + {_G_DOT}, 0.92 * {_G_RING} + {_G_DOT}, {_G_RING} + {_G_DOT})
+  }}
+}}'''
+
+# dist/layered-scene.js: gradient mix((0, 0.02, 0.15), (0, 0, 0.1), length(uv)); ring(0.35, 0.03) glow glow_i tint
+# (0, 1, 1); circle(0.08) glow orb_glow tint (0.831, 0.686, 0.216); layers added.
+_L_RING, _L_DOT = RING.format(t="0.03", i="0.5"), DOT.format(r="0.08", i="1.0")
+LAYERED = f'''cinematic "layered-as-rendered" {{
+  layer {{
+    fn: circle(10.0) | shade(0.831 * {_L_DOT},
+                             mix(0.02, 0.0, length(uv)) + {_L_RING} + 0.686 * {_L_DOT},
+                             mix(0.15, 0.1, length(uv)) + {_L_RING} + 0.216 * {_L_DOT})
+  }}
+}}'''
+
+CASES = [("gauge_component", GAUGE), ("gauge_pane", GAUGE), ("layered_component", LAYERED), ("layered_pane", LAYERED)]
+
+
+def _crops():
+    return np.load(os.path.join(HERE, "golden", "reference_screenshots.npz"))
+
+
+def _mask(h, w):
+    """True where the canvas shows through: the preview pane carries a label at its top left and an fps counter at
+    its bottom right; the component canvas carries nothing."""
+    m = np.ones((h, w), dtype=bool)
+    if w > 200:
+        m[:24, :100] = False
+        m[h - 30:, 630:] = False
+    return m
+
+
+def _compare(frame, crop):
+    h, w, _ = crop.shape
+    d = np.abs(frame[:, :, :3].astype(np.int32) - crop.astype(np.int32))[_mask(h, w)]
+    assert d.max() <= 1, f"a channel is {d.max()} levels from the reference's pixel"
+    assert (d == 0).mean() >= 0.95
+    assert np.all(frame[:, :, 3] == 255)
+    return (d == 0).mean()
+
+
+@pytest.mark.parametrize("name,src", CASES)
+def test_oracle_reproduces_the_reference_screenshot(game, oracle, name, src):
+    crop = _crops()[name]
+    h, w, _ = crop.shape
+    cin = game.compile(src).cinematics[0]
+    assert cin.pixel_expr_count == 3 and cin.derived_count == 0
+    row = cin.uniform_rows([0.0], w, h)[0]
+    for semantics in ("glsl", "wgsl"):
+        _compare(oracle.render(cin.blob, w, h, row, semantics=semantics, animate=True), crop)
+    # without the opt-in the expressions fall back to the parameter defaults, as the reference resolves them
+    plain = oracle.render(cin.blob, w, h, row)
+    assert np.abs(plain[:, :, :3].astype(np.int32) - crop.astype(np.int32)).max() > 100
+
+
+def test_the_overlay_mask_is_what_keeps_the_pane_from_matching(game, oracle):
+    crop = _crops()["gauge_pane"]
+    h, w, _ = crop.shape
+    cin = game.compile(GAUGE).cinematics[0]
+    frame = oracle.render(cin.blob, w, h, cin.uniform_rows([0.0], w, h)[0], animate=True)
+    d = np.abs(frame[:, :, :3].astype(np.int32) - crop.astype(np.int32)).max(axis=2)
+    assert d[_mask(h, w)].max() <= 1 and d[~_mask(h, w)].max() > 30      # the label and the counter, nothing else
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,src", CASES)
+def test_gpu_reproduces_the_reference_screenshot(game, oracle, name, src):
+    crop = _crops()[name]
+    h, w, _ = crop.shape
+    cin = game.compile(src).cinematics[0]
+    rows = cin.uniform_rows([0.0], w, h)
+    for semantics in ("glsl", "wgsl"):
+        r = cin.renderer(w, h, semantics=semantics, animate=True)
+        got = r.render(rows)[0]
+        r.close()
+        _compare(got, crop)
+        assert np.array_equal(got, oracle.render(cin.blob, w, h, rows[0], semantics=semantics, animate=True))
