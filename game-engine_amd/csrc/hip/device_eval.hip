@@ -15,15 +15,17 @@ namespace {
 enum EvalOp { EV_FRACT = 0, EV_SIN, EV_COS, EV_ATAN2, EV_HASH2, EV_NOISE2, EV_SIMPLEX, EV_VORONOI, EV_EXP2, EV_LOG2, EV_POW,
               EV_MAX, EV_MIN, EV_FBM6, EV_SQRT, EV_DIV, EV_SMOOTHSTEP_GLOW, EV_MOD, EV_UNORM8, EV_NOISE2_LUT, EV_FBM6_LUT, EV_VORONOI_LUT, EV_SIMPLEX_LUT, EV_PACK_UNORM8, EV_RSQRT, EV_COUNT };
 
-// Fills the lattice-hash table: entry (row iy + 512, column ix + 512) = {hash2(ix, iy), hash2(ix, iy + 1)}.
+// Fills the lattice-hash table: entry (row iy + 512, column ix + 512) = the corners of the cell at (ix, iy) as
+// gd_corners_hash makes them: {h(ix, iy), h(ix, iy + 1), h(ix + 1, iy) - h(ix, iy), h(ix + 1, iy + 1) - h(ix, iy + 1)}.
 __global__ void hash_lut_fill(float* __restrict__ table)
 {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
     if (u >= GD_LUT_ROWS) return;
-    const float x = (float)((int)u - GD_LUT_HALF), y = (float)((int)v - GD_LUT_HALF);
-    float* e = table + ((size_t)v * GD_LUT_STRIDE + u) * 2u;
-    e[0] = gd_hash2(x, y);
-    e[1] = gd_hash2(x, y + 1.0f);
+    GdCell c;
+    c.ix = (float)((int)u - GD_LUT_HALF); c.iy = (float)((int)v - GD_LUT_HALF);
+    const GdCorners k = gd_corners_hash(c);
+    float* e = table + ((size_t)v * GD_LUT_STRIDE + u) * 4u;
+    e[0] = k.a; e[1] = k.c; e[2] = k.ab; e[3] = k.cd;
 }
 
 // Fills the voronoi table: entry (row cy + 512, column cx + 512) = the cell's feature point (glsl.rs:211-214).
@@ -200,8 +202,9 @@ int lut_for_current_device(int kind, const float** table)
     auto it = tables.find(dev);
     if (it == tables.end()) {
         float* t = nullptr;
+        // lattice hashes: 16-byte entries; voronoi feature points: 8-byte entries
         const size_t bytes = kind == 2 ? (size_t)GD_SIMPLEX_DIM * GD_SIMPLEX_DIM * 4u * sizeof(float)
-                                       : (size_t)GD_LUT_ROWS * GD_LUT_STRIDE * 2u * sizeof(float);
+                                       : (size_t)GD_LUT_ROWS * GD_LUT_STRIDE * (kind == 0 ? 4u : 2u) * sizeof(float);
         HIP_TRY(hipMalloc((void**)&t, bytes));
         hipError_t e = hipMemset(t, 0, bytes);
         if (e == hipSuccess) {

@@ -20,6 +20,7 @@ typedef unsigned int gd_u32;
 typedef const __attribute__((address_space(4))) float* gd_uniform_row;
 typedef gd_u32 gd_u32x4 __attribute__((ext_vector_type(4)));
 typedef float gd_f32x2 __attribute__((ext_vector_type(2)));
+typedef float gd_f32x4 __attribute__((ext_vector_type(4)));
 typedef float gd_f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));   // 16-byte load at 8-byte alignment
 
 // ── scalar helpers ──────────────────────────────────────────────────────────────────────
@@ -139,7 +140,9 @@ GD float gd_step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
 GD float gd_ceil(float x) { return -gd_floor(-x); }
 GD float gd_round(float x) { return __builtin_rintf(x); }   // to nearest, ties to even (v_rndne_f32)
 GD float gd_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
-GD float gd_mix(float a, float b, float t) { return __builtin_fmaf(b, t, a * (1.0f - t)); }
+// mix(a, b, t) as a + t (b - a): one subtraction and one fused multiply-add (GLSL gives x (1 - t) + y t as the formula and
+// leaves the evaluation to the implementation; this is the form that needs no 1 - t).
+GD float gd_mix(float a, float b, float t) { return __builtin_fmaf(t, b - a, a); }
 GD float gd_smoothstep(float e0, float e1, float x)
 {
     float t = gd_clamp((x - e0) * gd_rcp(e1 - e0), 0.0f, 1.0f);
@@ -325,25 +328,34 @@ GD float gd_noise2(float px, float py)
 // Lattice-hash table. hash2 is a pure function of the lattice point, and a frame touches only a few
 // thousand distinct points per octave while every pixel needs four of them per noise2 call, so the
 // runtime tabulates hash2 over the integer points of [-512, 512]^2 once per device. Entry (iy + 512,
-// ix + 512) holds the pair {hash2(ix, iy), hash2(ix, iy + 1)} (GD_LUT_STRIDE pairs per row), so the four
-// corners of a cell are one 16-byte load; noise2 then costs one range test, a three-instruction index
-// and that load instead of four hash evaluations. Points outside the table, and a null table,
-// take the arithmetic path; both paths return the same bits because the table is filled by gd_hash2.
+// ix + 512) holds what the cell whose lower left corner is (ix, iy) needs (GD_LUT_STRIDE entries of 16 bytes per row):
+// {a, c, b - a, d - c} with a = hash2(ix, iy), b = hash2(ix + 1, iy), c = hash2(ix, iy + 1), d = hash2(ix + 1, iy + 1) -
+// the two left corners and the two differences that mix(a, b, ux) = a + ux (b - a) and mix(c, d, ux) start from, each
+// difference rounded once as the subtraction in gd_mix rounds it. noise2 then costs one range test, a three-instruction
+// index and one 16-byte load instead of four hash evaluations and two subtractions. Points outside the table, and a
+// null table, take the arithmetic path; both paths return the same bits because the table is filled by gd_hash2 and
+// the same subtraction.
 #define GD_LUT_STRIDE 2048u
 #define GD_LUT_ROWS 1025u
 #define GD_LUT_HALF 512
 // One noise2 evaluation split in two, so that callers needing several values (the fbm octaves, the two
 // components of a warp) can test all their lattice cells first, issue all table loads back to back, and
 // only then combine: the loads of one call overlap instead of each waiting out its own latency.
-// Byte offset of table entry (iy + 512 + d, ix + 512 + d) for integral ix, iy inside the table and d = 0 or -1.
+// Byte offset of table entry (iy + 512 + d, ix + 512 + d) for integral ix, iy inside the table and d = 0 or -1, in a table
+// of 8-byte entries (gd_lut_offset: the voronoi feature points) or 16-byte entries (gd_lut_offset16: the lattice hashes).
 // The entry number k = (iy + 512 + d) * 2048 + (ix + 512 + d) is computed in floating point: iy * 2048 + ix is
 // exact (below 2^21), adding 1.5 * 2^23 + (512 + d) * 2049 is exact too and leaves 0x4B400000 + k in the bits;
-// shifting left by 3 drops the exponent's top bits, and subtracting what is left of them gives 8 k.
+// shifting left by 3 (or 4) drops the exponent's top bits, and subtracting what is left of them gives 8 k (16 k).
 // Three instructions: fma, add, shift-and-add.
 GD gd_u32 gd_lut_offset(float ix, float iy, float d)
 {
     const float t = __builtin_fmaf(iy, 2048.0f, ix);
     return (gd_bits(t + (12582912.0f + (512.0f + d) * 2049.0f)) << 3) - 0x5A000000u;
+}
+GD gd_u32 gd_lut_offset16(float ix, float iy, float d)
+{
+    const float t = __builtin_fmaf(iy, 2048.0f, ix);
+    return (gd_bits(t + (12582912.0f + (512.0f + d) * 2049.0f)) << 4) - 0xB4000000u;
 }
 struct GdCell {
     float ix, iy;    // lattice cell
@@ -359,29 +371,34 @@ GD GdCell gd_cell(float px, float py)
     c.ux = fx * fx * __builtin_fmaf(-2.0f, fx, 3.0f);
     c.uy = fy * fy * __builtin_fmaf(-2.0f, fy, 3.0f);
     c.ok = gd_abs(c.ix) <= 511.0f && gd_abs(c.iy) <= 511.0f;
-    c.off = gd_lut_offset(c.ix, c.iy, 0.0f);
+    c.off = gd_lut_offset16(c.ix, c.iy, 0.0f);
     return c;
 }
-struct GdCorners { float a, b, c, d; };
+// The left corners of a cell and the differences to their right neighbours: a = h(x, y), c = h(x, y + 1),
+// ab = h(x + 1, y) - a, cd = h(x + 1, y + 1) - c.
+struct GdCorners { float a, c, ab, cd; };
 GD GdCorners gd_corners_load(const GdCell& c, const float* __restrict__ lut)
 {
-    const gd_f32x4_a8 t = *(const gd_f32x4_a8*)((const char*)lut + c.off);   // {h(x,y), h(x,y+1), h(x+1,y), h(x+1,y+1)}
+    const gd_f32x4 t = *(const gd_f32x4*)((const char*)lut + c.off);
     GdCorners k;
-    k.a = t[0]; k.c = t[1]; k.b = t[2]; k.d = t[3];
+    k.a = t[0]; k.c = t[1]; k.ab = t[2]; k.cd = t[3];
     return k;
 }
 GD GdCorners gd_corners_hash(const GdCell& c)
 {
     GdCorners k;
     k.a = gd_hash2(c.ix, c.iy);
-    k.b = gd_hash2(c.ix + 1.0f, c.iy);
     k.c = gd_hash2(c.ix, c.iy + 1.0f);
-    k.d = gd_hash2(c.ix + 1.0f, c.iy + 1.0f);
+    k.ab = gd_hash2(c.ix + 1.0f, c.iy) - k.a;
+    k.cd = gd_hash2(c.ix + 1.0f, c.iy + 1.0f) - k.c;
     return k;
 }
+// mix(a, b, ux) and mix(c, d, ux): the x-interpolated values on the lower and the upper edge of the cell
+GD float gd_edge_lo(const GdCorners& k, float ux) { return __builtin_fmaf(ux, k.ab, k.a); }
+GD float gd_edge_hi(const GdCorners& k, float ux) { return __builtin_fmaf(ux, k.cd, k.c); }
 GD float gd_noise2_combine(const GdCell& c, const GdCorners& k)
 {
-    return __builtin_fmaf(gd_mix(gd_mix(k.a, k.b, c.ux), gd_mix(k.c, k.d, c.ux), c.uy), 2.0f, -1.0f);
+    return __builtin_fmaf(gd_mix(gd_edge_lo(k, c.ux), gd_edge_hi(k, c.ux), c.uy), 2.0f, -1.0f);
 }
 GD float gd_noise2_lut(float px, float py, const float* __restrict__ lut)
 {
@@ -401,6 +418,67 @@ GD void gd_noise2_pair_lut(float ax, float ay, float bx, float by, const float* 
     na = gd_noise2_combine(ca, ka); nb = gd_noise2_combine(cb, kb);
 }
 
+// The lattice cells of fbm2's octaves (glsl.rs:161-167): octave i samples at q_i * frequency_i with q_0 = p,
+// q_(i+1) = rot q_i and frequency_i = lacunarity^i. `first`: cells below that octave are left to the caller.
+// folded: with a lacunarity that is a power of two the sample point Q_i = q_i * frequency_i can be carried instead of
+// q_i - Q_(i+1) = (lacunarity rot) Q_i, the rotation's constants scaled exactly - which saves the two multiplications by
+// the frequency in every octave. Scaling by a power of two commutes with every rounding of the recurrence as long as no
+// intermediate is subnormal or overflows, so the cells are the same bits; gd_fbm_table_ok admits the folded form only
+// where that holds.
+GD bool gd_fbm_folds(float lacunarity)
+{
+    return __builtin_constant_p(lacunarity) && (lacunarity == 1.0f || lacunarity == 2.0f || lacunarity == 4.0f || lacunarity == 8.0f);
+}
+GD void gd_fbm_cells(float px, float py, int octaves, float lacunarity, int first, GdCell* cell, bool folded)
+{
+    if (folded) {
+        const float c8 = 0.8f * lacunarity, c6 = 0.6f * lacunarity;   // exact: lacunarity is a power of two
+        float Qx = px, Qy = py;
+#pragma unroll
+        for (int i = 0; i < octaves; i++) {
+            if (i >= first) cell[i] = gd_cell(Qx, Qy);
+            float nx = __builtin_fmaf(Qx, c8, -(Qy * c6));
+            float ny = __builtin_fmaf(Qx, c6, Qy * c8);
+            Qx = nx; Qy = ny;
+        }
+        return;
+    }
+    float frequency = 1.0f, qx = px, qy = py;
+#pragma unroll
+    for (int i = 0; i < octaves; i++) {
+        if (i >= first) cell[i] = gd_cell(qx * frequency, qy * frequency);
+        frequency = frequency * lacunarity;
+        float nx = __builtin_fmaf(qx, 0.8f, -(qy * 0.6f));
+        float ny = __builtin_fmaf(qx, 0.6f, qy * 0.8f);
+        qx = nx; qy = ny;
+    }
+}
+// Amplitudes and their sum, and the test that lets all octaves read the table. One range test for all octaves: octave i
+// samples at (rotation^i p) * frequency_i, whose Euclidean norm is |p| * frequency_i up to a few ulps, so
+// |p|^2 * max(frequency)^2 <= 509^2 keeps every lattice cell of every octave within [-510, 510] (two cells of margin
+// inside the table; NaN fails the test). Where the folded recurrence will be used both coordinates must also be at
+// least 2^-40 in size: then one of q's coordinates stays above 2^-41 through every rotation (they preserve the norm), a
+// product with 0.8 or 0.6 is never subnormal, and a difference that cancels is zero or at least 2^-88 - nothing is
+// subnormal in either form, so the folded and the literal cells agree bit for bit. (A coordinate of exactly zero would
+// be fine too; it takes the other path with the tiny ones, which costs the centre row and column of an odd-sized frame
+// a few hash evaluations.)
+GD bool gd_fbm_table_ok(float px, float py, int octaves, float persistence, float lacunarity, float* amp, float& max_val)
+{
+    float amplitude = 1.0f, frequency = 1.0f, fmax = 1.0f;
+    max_val = 0.0f;
+#pragma unroll
+    for (int i = 0; i < octaves; i++) {
+        fmax = !(gd_abs(frequency) <= fmax) ? gd_abs(frequency) : fmax;   // a NaN frequency makes fmax NaN: the test fails
+        amp[i] = amplitude;
+        max_val = max_val + amplitude;
+        amplitude = amplitude * persistence;
+        frequency = frequency * lacunarity;
+    }
+    bool ok = __builtin_fmaf(px, px, py * py) * (fmax * fmax) <= 259081.0f;
+    if (gd_fbm_folds(lacunarity)) ok = ok && gd_min(gd_abs(px), gd_abs(py)) >= 0x1p-40f;
+    return ok;
+}
+
 GD int gd_octaves(float o)   // int(x), clamped to [0, 32]
 {
     if (!(o >= 1.0f)) return 0;
@@ -414,30 +492,16 @@ GD float gd_fbm2(float px, float py, int octaves, float persistence, float lacun
 {
     if (lut != nullptr && __builtin_constant_p(octaves) && octaves >= 1 && octaves <= 8) {
         // literal octave count: all cells first, then (when every cell is inside the table) all loads, then the sum
-        // One range test for all octaves: octave i samples at (rotation^i p) * frequency_i, whose Euclidean norm
-        // is |p| * frequency_i up to a few ulps, so |p|^2 * max(frequency)^2 <= 509^2 keeps every lattice cell of
-        // every octave within [-510, 510] (two cells of margin inside the table; NaN fails the test).
         GdCell cell[8];
         float amp[8];
-        float amplitude = 1.0f, frequency = 1.0f, max_val = 0.0f, qx = px, qy = py, fmax = 1.0f;
-#pragma unroll
-        for (int i = 0; i < octaves; i++) {
-            cell[i] = gd_cell(qx * frequency, qy * frequency);
-            fmax = !(gd_abs(frequency) <= fmax) ? gd_abs(frequency) : fmax;   // a NaN frequency makes fmax NaN: the test fails
-            amp[i] = amplitude;
-            max_val = max_val + amplitude;
-            amplitude = amplitude * persistence;
-            frequency = frequency * lacunarity;
-            float nx = __builtin_fmaf(qx, 0.8f, -(qy * 0.6f));
-            float ny = __builtin_fmaf(qx, 0.6f, qy * 0.8f);
-            qx = nx; qy = ny;
-        }
-        const bool ok = __builtin_fmaf(px, px, py * py) * (fmax * fmax) <= 259081.0f;
+        float max_val = 0.0f;
         GdCorners k[8];
-        if (ok) {
+        if (gd_fbm_table_ok(px, py, octaves, persistence, lacunarity, amp, max_val)) {
+            gd_fbm_cells(px, py, octaves, lacunarity, 0, cell, gd_fbm_folds(lacunarity));
 #pragma unroll
             for (int i = 0; i < octaves; i++) k[i] = gd_corners_load(cell[i], lut);
         } else {
+            gd_fbm_cells(px, py, octaves, lacunarity, 0, cell, false);
 #pragma unroll
             for (int i = 0; i < octaves; i++) k[i] = gd_corners_hash(cell[i]);
         }
@@ -724,21 +788,22 @@ GD void gb_domain_warp(GdPix& s, float amount, float freq)                      
 // p. Its x half, and with it the lattice column and the Hermite weight ux of both noise samples, is the same on every row
 // of the lane; its y half is the same for every lane of the workgroup, so one lane per row works it out once
 // (gd_warp_rows_y, into shared memory) and the others read it; and the lattice row changes once in hundreds of image
-// rows, so the two x-interpolated edge values of a cell (mix(a, b, ux) and mix(c, d, ux)) are kept from row to row and
-// fetched again only when the sample enters another lattice row. Every value is computed by the same operations as in
+// rows, so the x-interpolated value on the cell's lower edge (mix(a, b, ux)) and its difference to the one on the upper
+// edge (mix(c, d, ux) - mix(a, b, ux), the subtraction the outer mix starts with) are kept from row to row and fetched
+// again only when the sample enters another lattice row. Every value is computed by the same operations as in
 // gb_domain_warp, so the result is the same.
-struct GdWarpRows { float iy0, iy1, lo0, hi0, lo1, hi1; };
-struct __attribute__((aligned(16))) GdWarpY { float iy0, uy0, om0, iy1, uy1, om1, ok, pad; };   // y halves of both samples; om = 1 - uy
-GD void gd_warp_rows_reset(GdWarpRows& k) { k.iy0 = k.iy1 = __builtin_nanf(""); k.lo0 = k.hi0 = k.lo1 = k.hi1 = 0.0f; }
+struct GdWarpRows { float iy0, iy1, lo0, d0, lo1, d1; };
+struct __attribute__((aligned(16))) GdWarpY { float iy0, uy0, iy1, uy1, ok, pad0, pad1, pad2; };   // y halves of both samples
+GD void gd_warp_rows_reset(GdWarpRows& k) { k.iy0 = k.iy1 = __builtin_nanf(""); k.lo0 = k.d0 = k.lo1 = k.d1 = 0.0f; }
 GD void gd_warp_rows_y(float py, float freq, float* o)
 {
     const float a = py * freq, b = py * freq + 1.3f;
     const float iy0 = gd_floor(a), f0 = gd_fract(a), iy1 = gd_floor(b), f1 = gd_fract(b);
     const float uy0 = f0 * f0 * __builtin_fmaf(-2.0f, f0, 3.0f), uy1 = f1 * f1 * __builtin_fmaf(-2.0f, f1, 3.0f);
-    o[0] = iy0; o[1] = uy0; o[2] = 1.0f - uy0;
-    o[3] = iy1; o[4] = uy1; o[5] = 1.0f - uy1;
-    o[6] = (gd_abs(iy0) <= 511.0f && gd_abs(iy1) <= 511.0f) ? 1.0f : 0.0f;
-    o[7] = 0.0f;
+    o[0] = iy0; o[1] = uy0;
+    o[2] = iy1; o[3] = uy1;
+    o[4] = (gd_abs(iy0) <= 511.0f && gd_abs(iy1) <= 511.0f) ? 1.0f : 0.0f;
+    o[5] = o[6] = o[7] = 0.0f;
 }
 GD void gb_domain_warp_rows(GdPix& s, float amount, float freq, GdWarpRows& k, const GdWarpY& y)
 {
@@ -753,17 +818,17 @@ GD void gb_domain_warp_rows(GdPix& s, float amount, float freq, GdWarpRows& k, c
     float n0, n1;
     if (s.lut != nullptr && gd_abs(ca.ix) <= 511.0f && gd_abs(cb.ix) <= 511.0f && y.ok != 0.0f) {
         if (ca.iy != k.iy0) {
-            ca.off = gd_lut_offset(ca.ix, ca.iy, 0.0f);
+            ca.off = gd_lut_offset16(ca.ix, ca.iy, 0.0f);
             GdCorners c = gd_corners_load(ca, s.lut);
-            k.lo0 = gd_mix(c.a, c.b, ca.ux); k.hi0 = gd_mix(c.c, c.d, ca.ux); k.iy0 = ca.iy;
+            k.lo0 = gd_edge_lo(c, ca.ux); k.d0 = gd_edge_hi(c, ca.ux) - k.lo0; k.iy0 = ca.iy;
         }
         if (cb.iy != k.iy1) {
-            cb.off = gd_lut_offset(cb.ix, cb.iy, 0.0f);
+            cb.off = gd_lut_offset16(cb.ix, cb.iy, 0.0f);
             GdCorners c = gd_corners_load(cb, s.lut);
-            k.lo1 = gd_mix(c.a, c.b, cb.ux); k.hi1 = gd_mix(c.c, c.d, cb.ux); k.iy1 = cb.iy;
+            k.lo1 = gd_edge_lo(c, cb.ux); k.d1 = gd_edge_hi(c, cb.ux) - k.lo1; k.iy1 = cb.iy;
         }
-        n0 = __builtin_fmaf(__builtin_fmaf(k.hi0, y.uy0, k.lo0 * y.om0), 2.0f, -1.0f);   // mix(lo, hi, uy) * 2 - 1
-        n1 = __builtin_fmaf(__builtin_fmaf(k.hi1, y.uy1, k.lo1 * y.om1), 2.0f, -1.0f);
+        n0 = __builtin_fmaf(__builtin_fmaf(y.uy0, k.d0, k.lo0), 2.0f, -1.0f);   // mix(lo, hi, uy) * 2 - 1
+        n1 = __builtin_fmaf(__builtin_fmaf(y.uy1, k.d1, k.lo1), 2.0f, -1.0f);
     } else {
         n0 = gd_noise2_combine(ca, gd_corners_hash(ca));
         n1 = gd_noise2_combine(cb, gd_corners_hash(cb));
@@ -819,13 +884,13 @@ GD void gb_voronoi_rows(GdPix& s, float scale, GdVoronoiRows& k, const float* y)
 }
 // fbm with a literal octave count: octave 0 samples at p * scale itself (the rotation starts with octave 1), so its
 // lattice column, its x weight and - from row to row - its x-interpolated edge values stay.
-struct GdFbmRows { float iy, lo, hi; };
-GD void gd_fbm_rows_reset(GdFbmRows& k) { k.iy = __builtin_nanf(""); k.lo = k.hi = 0.0f; }
-GD void gd_fbm_rows_y(float py, float scale, float* o)   // {lattice row, uy, 1 - uy, -} of octave 0
+struct GdFbmRows { float iy, lo, d; };   // lattice row, mix(a, b, ux), mix(c, d, ux) - mix(a, b, ux) of octave 0
+GD void gd_fbm_rows_reset(GdFbmRows& k) { k.iy = __builtin_nanf(""); k.lo = k.d = 0.0f; }
+GD void gd_fbm_rows_y(float py, float scale, float* o)   // {lattice row, uy, -, -} of octave 0
 {
     const float a = py * scale;
     const float f = gd_fract(a);
-    o[0] = gd_floor(a); o[1] = f * f * __builtin_fmaf(-2.0f, f, 3.0f); o[2] = 1.0f - o[1]; o[3] = 0.0f;
+    o[0] = gd_floor(a); o[1] = f * f * __builtin_fmaf(-2.0f, f, 3.0f); o[2] = 0.0f; o[3] = 0.0f;
 }
 GD void gb_fbm_rows(GdPix& s, float scale, int octaves, float persistence, float lacunarity, GdFbmRows& k, const float* y)
 {
@@ -834,43 +899,31 @@ GD void gb_fbm_rows(GdPix& s, float scale, int octaves, float persistence, float
         s.sdf = gd_fbm2(px, py, octaves, persistence, lacunarity, s.lut);
         return;
     }
-    // as gd_fbm2's table path; cell 0 takes its y half from the workgroup's row values
+    // as gd_fbm2's table path; cell 0 (which samples at p * scale itself) takes its y half from the workgroup's row values
     GdCell cell[8];
     float amp[8];
-    float amplitude = 1.0f, frequency = 1.0f, max_val = 0.0f, qx = px, qy = py, fmax = 1.0f;
-#pragma unroll
-    for (int i = 0; i < octaves; i++) {
-        if (i == 0) {
-            const float fx = gd_fract(qx * frequency);
-            cell[0].ix = gd_floor(qx * frequency); cell[0].iy = y[0];
-            cell[0].ux = fx * fx * __builtin_fmaf(-2.0f, fx, 3.0f); cell[0].uy = y[1];
-        } else {
-            cell[i] = gd_cell(qx * frequency, qy * frequency);
-        }
-        fmax = !(gd_abs(frequency) <= fmax) ? gd_abs(frequency) : fmax;
-        amp[i] = amplitude;
-        max_val = max_val + amplitude;
-        amplitude = amplitude * persistence;
-        frequency = frequency * lacunarity;
-        float nx = __builtin_fmaf(qx, 0.8f, -(qy * 0.6f));
-        float ny = __builtin_fmaf(qx, 0.6f, qy * 0.8f);
-        qx = nx; qy = ny;
+    float max_val = 0.0f;
+    {
+        const float fx = gd_fract(px);
+        cell[0].ix = gd_floor(px); cell[0].iy = y[0];
+        cell[0].ux = fx * fx * __builtin_fmaf(-2.0f, fx, 3.0f); cell[0].uy = y[1];
     }
-    const bool ok = __builtin_fmaf(px, px, py * py) * (fmax * fmax) <= 259081.0f;
     float value = 0.0f;
-    if (ok) {
+    if (gd_fbm_table_ok(px, py, octaves, persistence, lacunarity, amp, max_val)) {
+        gd_fbm_cells(px, py, octaves, lacunarity, 1, cell, gd_fbm_folds(lacunarity));
         GdCorners c[8];
 #pragma unroll
         for (int i = 1; i < octaves; i++) c[i] = gd_corners_load(cell[i], s.lut);
         if (cell[0].iy != k.iy) {
-            cell[0].off = gd_lut_offset(cell[0].ix, cell[0].iy, 0.0f);
+            cell[0].off = gd_lut_offset16(cell[0].ix, cell[0].iy, 0.0f);
             GdCorners c0 = gd_corners_load(cell[0], s.lut);
-            k.lo = gd_mix(c0.a, c0.b, cell[0].ux); k.hi = gd_mix(c0.c, c0.d, cell[0].ux); k.iy = cell[0].iy;
+            k.lo = gd_edge_lo(c0, cell[0].ux); k.d = gd_edge_hi(c0, cell[0].ux) - k.lo; k.iy = cell[0].iy;
         }
-        value = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(k.hi, y[1], k.lo * y[2]), 2.0f, -1.0f), amp[0], value);
+        value = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(y[1], k.d, k.lo), 2.0f, -1.0f), amp[0], value);
 #pragma unroll
         for (int i = 1; i < octaves; i++) value = __builtin_fmaf(gd_noise2_combine(cell[i], c[i]), amp[i], value);
     } else {
+        gd_fbm_cells(px, py, octaves, lacunarity, 1, cell, false);
 #pragma unroll
         for (int i = 0; i < octaves; i++) value = __builtin_fmaf(gd_noise2_combine(cell[i], gd_corners_hash(cell[i])), amp[i], value);
     }
@@ -1062,14 +1115,14 @@ GD float gw_voronoi2(float px, float py, float scale, const float* __restrict__ 
     const bool table = lut != nullptr && gd_abs(ipx) <= 510.0f && gd_abs(ipy) <= 510.0f;
     float h[3][3];
     if (table) {
-        // rows ipy - 1 and ipy of the pair table hold {h(y-1), h(y)} and {h(y), h(y+1)} for columns ipx - 1 .. ipx + 1
-        const char* base = (const char*)lut + gd_lut_offset(ipx, ipy, -1.0f);
-        gd_f32x4_a8 lo01 = *(const gd_f32x4_a8*)base;
-        gd_f32x2 lo2 = *(const gd_f32x2*)(base + 16);
-        gd_f32x4_a8 hi01 = *(const gd_f32x4_a8*)(base + GD_LUT_STRIDE * 8u);
-        gd_f32x2 hi2 = *(const gd_f32x2*)(base + GD_LUT_STRIDE * 8u + 16);
-        h[0][0] = lo01[0]; h[1][0] = lo01[1]; h[0][1] = lo01[2]; h[1][1] = lo01[3]; h[0][2] = lo2[0]; h[1][2] = lo2[1];
-        h[2][0] = hi01[1]; h[2][1] = hi01[3]; h[2][2] = hi2[1];
+        // the entries of rows ipy - 1 and ipy start with {h(y-1), h(y)} and {h(y), h(y+1)}, for columns ipx - 1 .. ipx + 1
+        const char* base = (const char*)lut + gd_lut_offset16(ipx, ipy, -1.0f);
+#pragma unroll
+        for (int x = 0; x < 3; x++) {
+            const gd_f32x2 lo = *(const gd_f32x2*)(base + 16 * x);
+            const gd_f32x2 hi = *(const gd_f32x2*)(base + GD_LUT_STRIDE * 16u + 16 * x);
+            h[0][x] = lo[0]; h[1][x] = lo[1]; h[2][x] = hi[1];
+        }
     } else {
 #pragma unroll
         for (int y = 0; y < 3; y++)

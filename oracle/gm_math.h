@@ -55,7 +55,8 @@ static inline float gm_mod(float x, float y) { return x - y * floorf(x * gm_rcp(
 static inline float gm_step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
 /* Contraction points: GLSL leaves a*b+c contraction to the implementation; the render path fixes
  * them, so each place below that says fmaf is one fused rounding on every machine. */
-static inline float gm_mix(float a, float b, float t) { return fmaf(b, t, a * (1.0f - t)); }
+/* mix(a, b, t) = a + t (b - a): one subtraction, one fused multiply-add (GLSL words it x (1 - t) + y t and leaves the evaluation open) */
+static inline float gm_mix(float a, float b, float t) { return fmaf(t, b - a, a); }
 static inline float gm_smoothstep(float e0, float e1, float x)
 {
     float t = gm_clamp((x - e0) * gm_rcp(e1 - e0), 0.0f, 1.0f);

@@ -88,7 +88,10 @@ def fract(x):
 
 
 def mix(a, b, t):
-    return fma(b, t, a * (F(1.0) - t))
+    """a + t (b - a) with one fused multiply-add; literally, GLSL's x (1 - t) + y t."""
+    if LITERAL:
+        return (f(a) * (F(1.0) - f(t)) + f(b) * f(t)).astype(np.float32)
+    return fma(t, f(b) - f(a), a)
 
 
 def clamp(x, lo, hi):
