@@ -4,7 +4,11 @@
  * the shipped render path never does.
  *
  * PARITY UNPINNED: the reference holds no pixel or particle golden vectors (its tests assert on
- * emitted text only) and its executor (a browser GLSL/WGSL implementation) cannot run here. This
+ * emitted text only) and its executor (a browser GLSL/WGSL implementation) cannot run here. The only
+ * pixels of the reference's own in its tree, two dev-server screenshots rendered from an older
+ * generation's shader text, pin the prologue (pixel centres, uv, aspect, p), the expression
+ * functions and the RGBA8 store - not the builtins of today's emitter
+ * (tests/test_reference_screenshots.py: within one 8-bit level everywhere). This
  * file follows the emitted GLSL ES 3.00 text operation by operation, in scalar FP32, one rounding
  * per GLSL operator (compile with -ffp-contract=off), with the function definitions of gm_math.h.
  *
