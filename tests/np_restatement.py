@@ -1,6 +1,6 @@
-"""Independent numpy (float32, one rounding per operation) restatement of the parts of the emitted
-GLSL that use no transcendental function, written from game-compiler/src/codegen/glsl.rs without
-looking at the C oracle's structure. Used to cross-check oracle/game_oracle.c bit for bit; numpy
+"""Independent numpy (float32, one rounding per operation) restatement of the emitted GLSL of the
+benchmark cinematics (the sine of the hash stages as the render path defines it), written from
+game-compiler/src/codegen/glsl.rs without looking at the C oracle's structure. Used to cross-check oracle/game_oracle.c bit for bit; numpy
 float32 arithmetic is IEEE single precision with no fused operations; the places where the render
 path fixes a fused multiply-add (GLSL leaves contraction to the implementation) go through fma()
 below, which rounds once by way of float64 and round-to-odd.
@@ -137,6 +137,71 @@ def fbm2(px, py, octaves, persistence, lacunarity):  # glsl.rs:155-169
     return quotient(value, max_val)
 
 
+def sin32(x):
+    """sin as the render path defines it for |x| <= 32768 (GLSL leaves its precision open): k = rint(x / pi),
+    r = x - k pi by a three-constant Cody-Waite reduction with fma, sin = (-1)^k (r + r^3 P(r^2)), P of degree 3."""
+    x = f(x)
+    assert np.all(np.abs(x) <= F(32768.0))
+    k = np.rint(x * F(0.318309886))
+    r = fma(k, F(-3.140625), x)
+    r = fma(k, F(-9.67502593994140625e-4), r)
+    r = fma(k, F(-1.509957990978376432e-7), r)
+    z = r * r
+    ps = fma(fma(fma(F(float.fromhex("0x1.5c33e8p-19")), z, F(float.fromhex("-0x1.9f5196p-13"))), z, F(float.fromhex("0x1.110e1ap-7"))), z,
+             F(float.fromhex("-0x1.555546p-3")))
+    sn = fma(ps * z, r, r)
+    odd = (k.astype(np.int64) & 1).astype(np.uint32) << np.uint32(31)
+    return (sn.view(np.uint32) ^ odd).view(np.float32)
+
+
+def mod(x, y):
+    """GLSL mod(x, y) = x - y floor(x / y), the quotient by a constant as one reciprocal and one multiply."""
+    return (f(x) - F(y) * np.floor(quotient(x, F(y)))).astype(np.float32)
+
+
+def voronoi2d(px, py, scale):  # glsl.rs:201-220
+    psx, psy = px * F(scale), py * F(scale)
+    ipx, ipy = np.floor(psx), np.floor(psy)
+    fpx, fpy = fract(psx), fract(psy)
+    d = np.ones_like(px)
+    for y in (-1.0, 0.0, 1.0):
+        for x in (-1.0, 0.0, 1.0):
+            cx, cy = ipx + F(x), ipy + F(y)
+            hx = fract(sin32(cx * F(127.1) + cy * F(311.7)) * F(43758.5453))
+            hy = fract(sin32(cx * F(269.5) + cy * F(183.3)) * F(43758.5453))
+            ptx, pty = F(x) + hx - fpx, F(y) + hy - fpy
+            d = np.minimum(d, ptx * ptx + pty * pty)
+    return np.sqrt(d)
+
+
+def simplex2d(vx, vy):  # glsl.rs:172-199
+    Cx, Cy, Cz, Cw = F(0.211324865405187), F(0.366025403784439), F(-0.577350269189626), F(0.024390243902439)
+
+    def permute(x):
+        return mod((x * F(34.0) + F(1.0)) * x, 289.0)
+    s = vx * Cy + vy * Cy
+    ix, iy = np.floor(vx + s), np.floor(vy + s)
+    t = ix * Cx + iy * Cx
+    x0x, x0y = vx - ix + t, vy - iy + t
+    i1x = np.where(x0x > x0y, F(1.0), F(0.0)).astype(np.float32)
+    i1y = np.where(x0x > x0y, F(0.0), F(1.0)).astype(np.float32)
+    x1x, x1y = x0x + Cx - i1x, x0y + Cx - i1y
+    x2x, x2y = x0x + Cz, x0y + Cz
+    ix, iy = mod(ix, 289.0), mod(iy, 289.0)
+    pm = [permute(permute(iy + oy) + ix + ox) for oy, ox in ((F(0.0), F(0.0)), (i1y, i1x), (F(1.0), F(1.0)))]
+    m = [np.maximum(F(0.5) - (ax * ax + ay * ay), F(0.0)) for ax, ay in ((x0x, x0y), (x1x, x1y), (x2x, x2y))]
+    m = [mm * mm for mm in m]
+    m = [mm * mm for mm in m]
+    g = []
+    for k, (ax, ay) in enumerate(((x0x, x0y), (x1x, x1y), (x2x, x2y))):
+        xv = F(2.0) * fract(pm[k] * Cw) - F(1.0)
+        hh = np.abs(xv) - F(0.5)
+        a0 = xv - np.floor(xv + F(0.5))
+        m[k] = m[k] * (F(1.79284291400159) - F(0.85373472095314) * (a0 * a0 + hh * hh))
+        g.append(a0 * ax + hh * ay)
+    return F(130.0) * (m[0] * g[0] + m[1] * g[1] + m[2] * g[2])
+
+
 def apply_glow(d, intensity):  # glsl.rs:102-107
     i = F(intensity)
     core = smoothstep(0.005, -0.005, d)
@@ -204,6 +269,44 @@ def render_c3_no_grain(w, h, bass, mid, treble):
     r, b = r * (F(1.0) + dirx), b * (F(1.0) - dirx)
     fac = F(1.0) - smoothstep(0.8, F(0.8) + F(0.35), ln)
     return pack(r * fac, g * fac, b * fac, 1.0)
+
+
+def render_c3(w, h, bass, mid, treble, time):
+    """render_c3_no_grain followed by grain(0.025) (glsl.rs:453-457): every channel plus
+    (fract(sin(dot(p, (12.9898, 78.233)) + time) * 43758.5453) - 0.5) * amount; `time` is the wrapped shader time."""
+    uvx, uvy = pixel_grid(w, h)
+    sx = uvx * F(0.5) + F(0.5)
+    r = smoothstep(0.0, 0.33, sx) * (F(bass) + F(0.0))
+    g = smoothstep(0.33, 0.66, sx) * (F(mid) + F(0.0))
+    b = smoothstep(0.66, 1.0, sx) * (F(treble) + F(0.0))
+    lum = r * F(0.299) + g * F(0.587) + b * F(0.114)
+    add = np.maximum(lum - F(0.4), F(0.0)) * F(2.0)
+    r, g, b = r + add, g + add, b + add
+    d2 = fma(uvx, uvx, uvy * uvy)
+    ln = np.sqrt(d2)
+    dirx = (uvx * rsqrt(d2)) * F(0.6)
+    r, b = r * (F(1.0) + dirx), b * (F(1.0) - dirx)
+    fac = F(1.0) - smoothstep(0.8, F(0.8) + F(0.35), ln)
+    r, g, b = r * fac, g * fac, b * fac
+    px, py = uvx * (F(w) / F(h)), uvy
+    n = (fract(sin32(px * F(12.9898) + py * F(78.233) + F(time)) * F(43758.5453)) - F(0.5)) * F(0.025)
+    return pack(r + n, g + n, b + n, 1.0)
+
+
+def render_c2b(w, h):
+    """examples/tutorial-05-noise.game: three layers, screen-blended (glsl.rs:251-258), whose tint colours are user
+    uniforms at their default 0 with the builtin's defaults 1, 1 for the other two channels:
+    fbm(3.0, 4, 0.5, 2.0) | glow(1.5); simplex(4.0) | glow(1.2); voronoi(6.0) | glow(1.0); each | tint(0, 1, 1)."""
+    uvx, uvy = pixel_grid(w, h)
+    px, py = uvx * (F(w) / F(h)), uvy
+    glows = [apply_glow(fbm2(px * F(3.0), py * F(3.0), 4, 0.5, 2.0), 1.5),
+             apply_glow(simplex2d(px * F(4.0), py * F(4.0)), 1.2),
+             apply_glow(voronoi2d(px, py, 6.0), 1.0)]
+    fin = [np.zeros_like(px) for _ in range(3)]
+    for gl in glows:
+        lc = (gl * F(0.0), gl * F(1.0), gl * F(1.0))
+        fin = [fc + c - fc * c for fc, c in zip(fin, lc)]
+    return pack(fin[0], fin[1], fin[2], 1.0)
 
 
 def memory_mix(cur_rgba_float, prev_rgba8, decay):

@@ -126,6 +126,31 @@ def test_c3_frame_matches_numpy_without_grain(game, oracle):
     assert got[8, 16, 0] == 0 and got[8, 16, 2] == 0
 
 
+def test_c3_frame_matches_numpy_with_grain(game, oracle):
+    """The whole of examples/007-showcase.game, grain's sine hash included, at two times."""
+    audio = {"bass": 0.8, "mid": 0.6, "treble": 0.4, "energy": 0.6}
+    for t in (0.0, 2.75):
+        got, _ = frame(game, oracle, C3_SHOWCASE, 96, 54, t=t, audio=audio)
+        assert np.array_equal(got, NP.render_c3(96, 54, 0.8, 0.6, 0.4, t))          # t < 120: the wrapped time is t itself
+    assert not np.array_equal(NP.render_c3(96, 54, 0.8, 0.6, 0.4, 0.0), NP.render_c3_no_grain(96, 54, 0.8, 0.6, 0.4))
+
+
+@pytest.mark.parametrize("w,h", [(96, 54), (31, 40)])
+def test_c2b_frame_matches_numpy(game, oracle, w, h):
+    """examples/tutorial-05-noise.game: fbm, the permute-289 simplex, the sine-hash voronoi and the screen blend of
+    three layers, against the numpy statement of glsl.rs:155-220, :251-258."""
+    got, cin = frame(game, oracle, C2B_NOISE, w, h)
+    assert [n for n, _ in cin.uniforms] == ["frost", "ember", "violet"]
+    assert np.array_equal(got, NP.render_c2b(w, h))
+
+
+def test_sine_of_the_render_path_matches_numpy(oracle):
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.uniform(-32768, 32768, 20000), rng.uniform(-8, 8, 20000), [0.0, -0.0, 32768.0, -32768.0]]).astype(np.float32)
+    got = np.array([oracle.L.game_oracle_sin(float(v)) for v in x], dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), NP.sin32(x).view(np.uint32))
+
+
 def test_wgsl_semantics_post_chain_matches_numpy(game, oracle):
     """The WebGPU wording of spectrum / chromatic / vignette / tonemap (radial bands, additive fringe, mixed
     vignette, ACES) against an independent numpy statement of wgsl.rs."""
