@@ -118,7 +118,17 @@ def test_lattice_hash_table_path_equals_arithmetic_path(game):
     parts = [(rng.random((n, 2), dtype=np.float32) * 2 - 1) * np.float32(s) for s in (3.0, 200.0, 515.0, 5000.0, 3.0e7)]
     edge = np.array([[511.0, 0.5], [511.99, -511.99], [512.0, 3.0], [-512.0, 3.0], [-511.5, 511.5], [-512.01, 0.0], [0.0, 512.5],
                      [np.nan, 1.0], [1.0, np.nan], [np.inf, 0.0], [0.0, -np.inf], [-0.0, -0.0], [1e-40, -1e-40]], dtype=np.float32)
-    xy = np.concatenate(parts + [edge]).astype(np.float32)
+    # tiny coordinates: the table path of fbm carries the sample point through the octaves (no frequency multiplies) only
+    # where no intermediate of the literal recurrence can be subnormal - both coordinates at least 2^-40 in size; around
+    # that bound, far below it, subnormal, and with one coordinate tiny or zero beside an ordinary one
+    m = 20000
+    tiny = [(rng.random((m, 2), dtype=np.float32) * 2 - 1) * np.float32(s) for s in (2.0 ** -37, 2.0 ** -40, 2.0 ** -43, 1e-30, 3e-38, 1e-41)]
+    mixed = rng.random((m, 2), dtype=np.float32) * 2 - 1
+    mixed[: m // 2, 0] *= np.float32(2.0 ** -41)
+    mixed[m // 2:, 1] *= np.float32(1e-39)
+    mixed[::7, 1] = 0.0
+    mixed[3::11, 0] = -0.0
+    xy = np.concatenate(parts + tiny + [mixed, edge]).astype(np.float32)
     x, y = np.ascontiguousarray(xy[:, 0]), np.ascontiguousarray(xy[:, 1])
     for lut_op, op in (("noise2_lut", "noise2"), ("fbm6_lut", "fbm6"), ("voronoi2d_lut", "voronoi2d")):
         if op == "voronoi2d":        # scale 5: put the table edges (|floor| = 510, 511) inside the sample
