@@ -63,21 +63,39 @@ __device__ __forceinline__ uint32_t finish_sums(uint32_t rb, uint32_t ga)
     return rb | ga;
 }
 
+// Which 16-byte word of the tile (row ly of the LDS array, word c of its 18) lane tid moves in its k-th step. A 16-byte
+// LDS store is served in groups of 8 consecutive lanes and banked modulo 128 bytes (8 words of 16 bytes), so steps 0-3
+// give every group eight consecutive words of one row (words 0-7 or 8-15: 64 rows x 2 groups = 4 steps of 32 groups), and
+// step 4 moves the two words left over in every row: a group takes words 16 and 17 of rows r, r + 2, r + 4, r + 6, whose
+// starts (19 words apart per row) fall on distinct pairs of the eight.
+__device__ __forceinline__ void tile_word(uint32_t tid, uint32_t k, uint32_t& ly, uint32_t& c)
+{
+    if (k < 4u) {
+        const uint32_t grp = (tid >> 3) + 32u * k;
+        ly = grp >> 1;
+        c = 8u * (grp & 1u) + (tid & 7u);
+    } else {
+        const uint32_t oct = tid >> 3, j = tid & 7u;
+        ly = (oct >> 1) * 8u + (oct & 1u) + 2u * (j >> 1);       // tid < 128 only: 16 octets cover the 64 rows
+        c = 16u + (j & 1u);
+    }
+}
+
 // The tile's rows y0 - R .. y0 + CTY + R, columns x0 - 4 .. x0 + 67, as 16-byte words, clamped to the frame; all of a
 // lane's loads are issued before the first one is waited for (a fixed, unrolled count).
-template <int R, bool VEC, uint32_t NLOAD>
+template <int R, bool VEC>
 __device__ __forceinline__ void load_tile(const uint32_t* __restrict__ raw, uint32_t w, uint32_t h, int x0, int y0, uint32_t tid,
-                                                  u32x4 (&held)[NLOAD])
+                                          u32x4 (&held)[5])
 {
-    constexpr uint32_t CH = TX / 4u + 2u;                 // 16-byte chunks loaded per row
 #pragma unroll
-    for (uint32_t k = 0; k < NLOAD; ++k) {
-        const uint32_t i = tid + 256u * k;
-        const uint32_t ly = i / CH, c = i - ly * CH;
+    for (uint32_t k = 0; k < 5u; ++k) {
+        uint32_t ly, c;
+        tile_word(tid, k, ly, c);
         int gy = y0 - R + (int)ly;
         gy = gy < 0 ? 0 : (gy >= (int)h ? (int)h - 1 : gy);       // clamp to the frame's edge (also keeps idle lanes in range)
         const int gx = x0 - 4 + 4 * (int)c;
         const uint32_t* row = raw + (size_t)(uint32_t)gy * w;
+        if (k == 4u && tid >= 128u) { held[k] = u32x4{0u, 0u, 0u, 0u}; continue; }
         if (VEC && gx >= 0 && gx + 3 < (int)w) held[k] = *(const u32x4*)(row + gx);
         else {
 #pragma unroll
@@ -100,8 +118,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
                                                            uint32_t row0, uint32_t rows)
 {
     constexpr uint32_t IH = CTY + 2 * R;                  // rows of the horizontal pass: at most 64
-    constexpr uint32_t CH = TX / 4u + 2u;
-    constexpr uint32_t NLOAD = (CH * IH + 255u) / 256u;
     __shared__ __attribute__((aligned(16))) uint32_t in[IH][CSTRIDE];   // column 0 = frame column x0 - 4
     const uint32_t tid = threadIdx.x;
     // Workgroups are handed to the eight XCDs round robin, and each XCD has its own L2. Neighbouring tiles share their
@@ -113,20 +129,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
     const uint32_t tile = (blockIdx.x % 8u) * chunk + blockIdx.x / 8u;
     if (tile >= tiles) return;                            // the whole workgroup leaves, before any barrier
     const int x0 = (int)((tile % tiles_x) * TX), y0 = (int)(row0 + (tile / tiles_x) * CTY);
-    u32x4 held[NLOAD];
-    load_tile<R, VEC, NLOAD>(raw, w, h, x0, y0, tid, held);
+    u32x4 held[5];
+    load_tile<R, VEC>(raw, w, h, x0, y0, tid, held);
 #pragma unroll
-    for (uint32_t k = 0; k < NLOAD; ++k) {
-        const uint32_t i = tid + 256u * k;
-        const uint32_t ly = i / CH, c = i - ly * CH;
-        if (i < CH * IH) *(u32x4*)&in[ly][4u * c] = held[k];
+    for (uint32_t k = 0; k < 5u; ++k) {
+        uint32_t ly, c;
+        tile_word(tid, k, ly, c);
+        if (ly < IH && (k < 4u || tid < 128u)) *(u32x4*)&in[ly][4u * c] = held[k];
     }
     __syncthreads();
     // horizontal pass, in place: lane g of a row reads words 16 g .. 16 g + 23 and writes its 16 outputs over words
-    // 16 g + 4 .. 16 g + 19. The four lanes of a row are neighbours in one wave and all six reads of every lane are
-    // issued before any write (the empty asm below makes all six values a precondition of everything after it).
+    // 16 g + 4 .. 16 g + 19. The four lanes of a row sit in one 32-lane half of a wave and all six reads of every lane
+    // are issued before any write (the empty asm below makes all six values a precondition of everything after it).
+    // Which row and which quarter a lane takes: a 32-lane half works on eight rows, and with lane bits b0..b4
+    // g = b0 + 2 b2 and row = b1 + 2 (b2 xor b3) + 4 b4 both the 16-byte reads (16-lane groups {0-3, 12-15, 20-27} and
+    // {4-11, 16-19, 28-31}, banked modulo 16 words of 16 bytes) and the 16-byte stores (groups of 8 consecutive lanes,
+    // modulo 8 words) find every lane of a group on a different bank: rows are 19 words apart, and the word a lane reads
+    // or writes is 19 row + 4 g + constant (found by searching the bit-linear lane orders; the plain order - four
+    // consecutive lanes per row - reads without conflicts but stores 2-way).
     {
-        const uint32_t y = tid >> 2, g = tid & 3u;
+        const uint32_t g = (tid & 1u) | ((tid >> 1) & 2u);
+        const uint32_t y = (tid >> 5) * 8u + (((tid >> 1) & 1u) | ((((tid >> 2) ^ (tid >> 3)) & 1u) << 1) | (((tid >> 4) & 1u) << 2));
         if (y < IH) {
             const u32x4* src = (const u32x4*)&in[y][16u * g];
             u32x4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], q5 = src[5];
