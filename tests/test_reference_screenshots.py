@@ -92,6 +92,60 @@ def test_the_overlay_mask_is_what_keeps_the_pane_from_matching(game, oracle):
     assert d[_mask(h, w)].max() <= 1 and d[~_mask(h, w)].max() > 30      # the label and the counter, nothing else
 
 
+# Today's builtins against the same pixels, where the generations agree: the ring's distance function. In the screenshot
+# the track ring's term is exactly 1 wherever ring(0.35, 0.025) <= 0 and falls off as exp(-6.4 d) outside, so the red channel
+# equals round(255 (0.85 + centre-dot term)) inside the ring and is a level lower from d = 4e-4 on; today's
+# `ring(0.35, 0.025) | threshold(0.0) | shade(1, 1, 1)` is white exactly where the distance is negative. The two masks must
+# agree on every pixel of the annulus around the ring that is not within 1.5e-3 (an eighth of a pixel of the component
+# canvas, half a pixel of the pane) of one of its two edges: that puts `p`, the aspect factor, `length` and `ring` of the
+# v0.3.0 path on the reference's own pixels.
+EDGE = 'cinematic "edge" { layer { fn: ring(0.35, 0.025) | threshold(0.0) | shade(1.0, 1.0, 1.0) } }'
+
+
+def _ring_masks_agree(frame, crop):
+    h, w, _ = crop.shape
+    x = ((np.arange(w) + 0.5) / w * 2 - 1) * (w / h)
+    y = ((np.arange(h) + 0.5) / h * 2 - 1)[::-1]
+    ln = np.sqrt(x[None, :] ** 2 + y[:, None] ** 2)                    # float64 geometry, only to name the pixels near an edge
+    d = np.abs(ln - 0.35) - 0.025
+    dot = np.exp(-np.maximum(ln - 0.04, 0.0) * 1.5 * 8.0)
+    in_reference = crop[:, :, 0].astype(np.int32) >= np.rint(255 * (0.85 + dot)) - 1       # the browser's exp may sit one level lower
+    # white where the distance is negative; the WebGPU wording's threshold is step(cutoff, d) = 0 there, which shade turns
+    # into smoothstep's midpoint: grey 128 in place of white
+    in_ours = frame[:, :, 0] > 0
+    assert set(np.unique(frame[:, :, 0]).tolist()) in ({0, 255}, {0, 128})
+    annulus = (ln > 0.2) & (ln < 0.5) & _mask(h, w)
+    differ = (in_ours != in_reference) & annulus
+    assert in_ours[annulus].sum() > 1000 and (np.abs(d[differ]) < 1.5e-3).all()
+    assert differ.sum() <= (np.abs(d[annulus]) < 1.5e-3).sum()
+
+
+@pytest.mark.parametrize("name", ["gauge_component", "gauge_pane"])
+def test_oracle_ring_edges_fall_on_the_reference_pixels(game, oracle, name):
+    crop = _crops()[name]
+    h, w, _ = crop.shape
+    cin = game.compile(EDGE).cinematics[0]
+    assert cin.pixel_expr_count == 0 and cin.derived_count == 0          # plain v0.3.0 stages, no extension involved
+    for semantics in ("glsl", "wgsl"):
+        _ring_masks_agree(oracle.render(cin.blob, w, h, cin.uniform_rows([0.0], w, h)[0], semantics=semantics), crop)
+    # a ring half a percent larger no longer fits
+    other = game.compile(EDGE.replace("0.35", "0.352")).cinematics[0]
+    with pytest.raises(AssertionError):
+        _ring_masks_agree(oracle.render(other.blob, w, h, other.uniform_rows([0.0], w, h)[0]), crop)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["gauge_component", "gauge_pane"])
+def test_gpu_ring_edges_fall_on_the_reference_pixels(game, name):
+    crop = _crops()[name]
+    h, w, _ = crop.shape
+    cin = game.compile(EDGE).cinematics[0]
+    r = cin.renderer(w, h)
+    got = r.render(cin.uniform_rows([0.0], w, h))[0]
+    r.close()
+    _ring_masks_agree(got, crop)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,src", CASES)
 def test_gpu_reproduces_the_reference_screenshot(game, oracle, name, src):
