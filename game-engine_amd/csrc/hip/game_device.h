@@ -134,6 +134,20 @@ GD float gd_rcp(GdGuard& g, float y)
     if (gd_in_range(g, a >= 0x1p-126f && a < 0x1p126f)) return gd_rcp_core(y);
     return 1.0f / y;
 }
+// The same for a divisor known to be at least 1 unless it is not a number (the glow halo's 1 + 16 d^2 I^2): the lower
+// bound of the short form's range holds by construction, so one comparison decides (NaN and infinity fail it).
+GD float gd_rcp_ge1(float y)
+{
+    if (__builtin_constant_p(y)) return 1.0f / y;
+    if (gd_wave_all(y < 0x1p126f)) return gd_rcp_core(y);
+    return 1.0f / y;
+}
+GD float gd_rcp_ge1(GdGuard& g, float y)
+{
+    if (__builtin_constant_p(y)) return 1.0f / y;
+    if (gd_in_range(g, y < 0x1p126f)) return gd_rcp_core(y);
+    return 1.0f / y;
+}
 GD float gd_mod(float x, float y) { return x - y * gd_floor(x * gd_rcp(y)); }
 GD float gd_mod(GdGuard& g, float x, float y) { return x - y * gd_floor(x * gd_rcp(g, y)); }
 GD float gd_step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
@@ -641,14 +655,14 @@ GD float gd_apply_glow(float d, float intensity)   // glsl.rs:102-107
 {
     float core = gd_smoothstep(0.005f, -0.005f, d);
     // the halo quotient is one correctly rounded reciprocal and one multiply (the denominator is >= 1 or not finite)
-    float halo = intensity * gd_rcp(__builtin_fmaf(gd_max(d, 0.0f) * gd_max(d, 0.0f) * intensity * intensity, 16.0f, 1.0f));
+    float halo = intensity * gd_rcp_ge1(__builtin_fmaf(gd_max(d, 0.0f) * gd_max(d, 0.0f) * intensity * intensity, 16.0f, 1.0f));
     return core + halo;
 }
 
 GD float gd_apply_glow(GdGuard& g, float d, float intensity)
 {
     float core = gd_smoothstep(g, 0.005f, -0.005f, d);
-    float halo = intensity * gd_rcp(g, __builtin_fmaf(gd_max(d, 0.0f) * gd_max(d, 0.0f) * intensity * intensity, 16.0f, 1.0f));
+    float halo = intensity * gd_rcp_ge1(g, __builtin_fmaf(gd_max(d, 0.0f) * gd_max(d, 0.0f) * intensity * intensity, 16.0f, 1.0f));
     return core + halo;
 }
 
