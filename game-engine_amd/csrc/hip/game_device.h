@@ -651,18 +651,28 @@ GD float gd_voronoi2d_lut(float px, float py, float scale, const float* __restri
     return gd_sqrt(d);
 }
 
+// max(d, 0)^2 * I * I of the glow halo, evaluated left to right. With a literal intensity that is a power of two not
+// below 1 the two multiplications by I are exact scalings, so one multiplication by I^2 gives the same float (both forms
+// overflow to infinity together).
+GD float gd_glow_spread(float d, float intensity)
+{
+    const float m = gd_max(d, 0.0f);
+    if (__builtin_constant_p(intensity) && intensity >= 1.0f && intensity <= 0x1p60f && (gd_bits(intensity) & 0x007fffffu) == 0u)
+        return m * m * (intensity * intensity);
+    return m * m * intensity * intensity;
+}
 GD float gd_apply_glow(float d, float intensity)   // glsl.rs:102-107
 {
     float core = gd_smoothstep(0.005f, -0.005f, d);
     // the halo quotient is one correctly rounded reciprocal and one multiply (the denominator is >= 1 or not finite)
-    float halo = intensity * gd_rcp_ge1(__builtin_fmaf(gd_max(d, 0.0f) * gd_max(d, 0.0f) * intensity * intensity, 16.0f, 1.0f));
+    float halo = intensity * gd_rcp_ge1(__builtin_fmaf(gd_glow_spread(d, intensity), 16.0f, 1.0f));
     return core + halo;
 }
 
 GD float gd_apply_glow(GdGuard& g, float d, float intensity)
 {
     float core = gd_smoothstep(g, 0.005f, -0.005f, d);
-    float halo = intensity * gd_rcp_ge1(g, __builtin_fmaf(gd_max(d, 0.0f) * gd_max(d, 0.0f) * intensity * intensity, 16.0f, 1.0f));
+    float halo = intensity * gd_rcp_ge1(g, __builtin_fmaf(gd_glow_spread(d, intensity), 16.0f, 1.0f));
     return core + halo;
 }
 
