@@ -43,7 +43,7 @@ PEAK_HBM_GBS = 8000.0
 # 2.3 - 2.4 GHz after 35 - 85 ms of back-to-back launches. Every timed frame leg therefore first runs its own step,
 # untimed, for this many seconds (on top of the --warmup steps), so that what is timed is the steady state; the line
 # says so. (The particle legs need none: one step is 0.3 s of one kernel.)
-CLOCK_WARMUP_S = 0.3
+CLOCK_WARMUP_S = float(os.environ.get("GAME_BENCH_CLOCK_WARMUP_S", "0.3"))   # 0 for counter passes, which need no steady clock
 REHEARSE = os.environ.get("GAME_BENCH_REHEARSE") == "1"   # not a measurement mode: see dist_setup
 CONTROL_BACKEND = "nccl"    # what carries the barrier and the max over ranks at N > 1 (dist_setup may fall back to gloo)
 SIMDS, CLOCK_HZ = 1024, 2.4e9     # 256 CUs x 4 SIMDs; one wave64 VALU instruction per 2 cycles per SIMD at best
