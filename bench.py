@@ -173,16 +173,18 @@ def max_over_ranks(torch, world, value):
 def clock_warmup(step, sync, torch, world):
     """Runs `step` untimed for about CLOCK_WARMUP_S seconds. The number of repetitions is derived from the slowest
     rank's first step, so every rank runs the same number (a step may hold collectives)."""
+    step()                                  # the first step also pays for loading the code object
     sync()
     t0 = time.perf_counter()
     step()
     sync()
     one = max_over_ranks(torch, world, time.perf_counter() - t0)
-    reps = int(min(2000, max(0.0, CLOCK_WARMUP_S - one) / max(one, 1e-6)))
+    reps = int(min(5000, max(0.0, CLOCK_WARMUP_S - one) / max(one, 1e-6)))
+    t0 = time.perf_counter()
     for _ in range(reps):
         step()
     sync()
-    return round(one * (reps + 1), 3)
+    return round(one + time.perf_counter() - t0, 3)
 
 
 def cpu_baseline_frames(oracle, cin, cfg, rows, seconds_budget=20.0):
