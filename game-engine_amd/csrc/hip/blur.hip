@@ -20,8 +20,10 @@
 // three-operand or multiplying integer instruction issues at half rate on gfx950 - and measured 48.7 / 55.7 / 65.2 us per
 // 8K frame at radius 2 / 3 / 4 against 44.5 / 53.3 / 60.2 for this form; radius 1 is the same 41 us either way.)
 // A lane makes 16 adjacent pixels of a row in the horizontal pass (24 samples, six 16-byte LDS reads; four lanes per row,
-// up to 64 rows: one step for the whole workgroup) and 14 rows of one column in the vertical pass, where it streams its
-// samples through the cascade one at a time (2 x 8 blocks per lane measured 56 us per 8K frame at radius 4, this 53).
+// up to 64 rows: one step for the whole workgroup). In the vertical pass it makes a 2 x 8 block at radius 1 and 2; at radius 3
+// and 4 it takes 14 rows of one column and streams its samples through the cascade one at a time (8K frame at radius
+// 2 / 3 / 4: blocks 41.6 / 48.8 / 56.4 us, streamed 43.0 / 46.7 / 52.7 - the streamed form has fewer additions per output
+// but more, narrower loads and stores, which is what counts while the arithmetic is small).
 //
 // LDS layout. Rows are 19 slots of 16 bytes (the 18 in use and one of padding): with an odd number of slots per row the
 // four lanes of a row, which read slots 4 g + v, and the rows r .. r + 7 of a 32-lane half land on 16 distinct slots in
@@ -172,32 +174,69 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void b
         }
     }
     __syncthreads();
-    // vertical pass: a lane takes one column and 14 of the tile's 56 rows (64 columns x 4 blocks: all 256 lanes) and streams
-    // its 14 + 2R samples through the cascade one at a time - stage s keeps the value it saw last, so a sample costs 2R
-    // additions per channel pair and the state is 2R registers per pair, however long the run (the longer the run, the
-    // fewer additions per output: 2R + R (2R - 1) / 14 here). The rounds the first 2R samples cannot take part in fold
-    // away, the state starting from zero. 4-byte LDS reads of 64 consecutive words and 4-byte stores of 256 consecutive
-    // bytes per wave: no bank conflicts, whole lines.
-    {
-        constexpr int RUN = (int)(CTY / 4u);              // 14 output rows per lane
-        const uint32_t col = tid & 63u, by = (tid >> 6) * (uint32_t)RUN;
-        const uint32_t gx = (uint32_t)x0 + col;
-        uint32_t srb[2 * R], sga[2 * R];
-#pragma unroll
-        for (int s2 = 0; s2 < 2 * R; ++s2) srb[s2] = sga[s2] = 0u;
-#pragma unroll
-        for (int n = 0; n < RUN + 2 * R; ++n) {
-            const uint32_t p = in[by + (uint32_t)n][col + 4u];
-            uint32_t trb = p & 0x00ff00ffu, tga = (p >> 8) & 0x00ff00ffu;
-#pragma unroll
-            for (int s2 = 0; s2 < 2 * R; ++s2) {
-                const uint32_t yrb = trb + srb[s2], yga = tga + sga[s2];
-                srb[s2] = trb; sga[s2] = tga;
-                trb = yrb; tga = yga;
+    if constexpr (R <= 2) {
+        // vertical pass: a lane makes a block of 2 x 8 pixels from 8 + 2R rows of two words (8-byte LDS reads: the 32
+        // lanes of a half read one 256-byte run of a row, which no row stride can make collide), 32 lanes across the
+        // tile, seven block rows: 224 of the 256 lanes.
+        constexpr int CVB = 8;
+        const uint32_t bx = (tid & 31u) * 2u, by = (tid >> 5) * (uint32_t)CVB;
+        if (by < CTY) {
+            u32x2 colq[CVB + 2 * R];
+    #pragma unroll
+            for (int k = 0; k < CVB + 2 * R; ++k) colq[k] = *(const u32x2*)&in[by + (uint32_t)k][bx + 4u];
+            uint32_t o[2][CVB];
+    #pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                uint32_t rb[CVB + 2 * R], ga[CVB + 2 * R];
+    #pragma unroll
+                for (int k = 0; k < CVB + 2 * R; ++k) { const uint32_t p = colq[k][c]; rb[k] = p & 0x00ff00ffu; ga[k] = (p >> 8) & 0x00ff00ffu; }
+                cascade<R, CVB>(rb);
+                cascade<R, CVB>(ga);
+    #pragma unroll
+                for (int j = 0; j < CVB; ++j) o[c][j] = finish_sums<R>(rb[j], ga[j]);
             }
-            if (n >= 2 * R) {                             // the sum centred on row by + n - R of the array = output row by + n - 2R
-                const uint32_t gy = (uint32_t)y0 + by + (uint32_t)(n - 2 * R);
-                if (gy < row0 + rows && gx < w) out[(size_t)gy * w + gx] = finish_sums<R>(trb, tga);
+            const uint32_t gx = (uint32_t)x0 + bx;
+            const bool even = w % 2u == 0u && ((uintptr_t)out & 7u) == 0u;   // 8-byte stores need the rows on 8-byte boundaries
+    #pragma unroll
+            for (uint32_t j = 0; j < (uint32_t)CVB; ++j) {
+                const uint32_t gy = (uint32_t)y0 + by + j;
+                if (gy >= row0 + rows) break;
+                uint32_t* dst = out + (size_t)gy * w + gx;
+                if (even && gx + 1u < w) *(u32x2*)dst = u32x2{o[0][j], o[1][j]};
+                else {
+    #pragma unroll
+                    for (uint32_t c = 0; c < 2u; ++c) if (gx + c < w) dst[c] = o[c][j];
+                }
+            }
+        }
+    } else {
+        // vertical pass: a lane takes one column and 14 of the tile's 56 rows (64 columns x 4 blocks: all 256 lanes) and streams
+        // its 14 + 2R samples through the cascade one at a time - stage s keeps the value it saw last, so a sample costs 2R
+        // additions per channel pair and the state is 2R registers per pair, however long the run (the longer the run, the
+        // fewer additions per output: 2R + R (2R - 1) / 14 here). The rounds the first 2R samples cannot take part in fold
+        // away, the state starting from zero. 4-byte LDS reads of 64 consecutive words and 4-byte stores of 256 consecutive
+        // bytes per wave: no bank conflicts, whole lines.
+        {
+            constexpr int RUN = (int)(CTY / 4u);              // 14 output rows per lane
+            const uint32_t col = tid & 63u, by = (tid >> 6) * (uint32_t)RUN;
+            const uint32_t gx = (uint32_t)x0 + col;
+            uint32_t srb[2 * R], sga[2 * R];
+    #pragma unroll
+            for (int s2 = 0; s2 < 2 * R; ++s2) srb[s2] = sga[s2] = 0u;
+    #pragma unroll
+            for (int n = 0; n < RUN + 2 * R; ++n) {
+                const uint32_t p = in[by + (uint32_t)n][col + 4u];
+                uint32_t trb = p & 0x00ff00ffu, tga = (p >> 8) & 0x00ff00ffu;
+    #pragma unroll
+                for (int s2 = 0; s2 < 2 * R; ++s2) {
+                    const uint32_t yrb = trb + srb[s2], yga = tga + sga[s2];
+                    srb[s2] = trb; sga[s2] = tga;
+                    trb = yrb; tga = yga;
+                }
+                if (n >= 2 * R) {                             // the sum centred on row by + n - R of the array = output row by + n - 2R
+                    const uint32_t gy = (uint32_t)y0 + by + (uint32_t)(n - 2 * R);
+                    if (gy < row0 + rows && gx < w) out[(size_t)gy * w + gx] = finish_sums<R>(trb, tga);
+                }
             }
         }
     }
