@@ -309,6 +309,57 @@ def render_c2b(w, h):
     return pack(fin[0], fin[1], fin[2], 1.0)
 
 
+def voronoi2d_wgsl(px, py, scale):  # wgsl.rs:187-201
+    """The WebGPU emitter's cell noise: one arithmetic hash per cell gives the feature point (h, fract(17 h))."""
+    spx, spy = px * F(scale), py * F(scale)
+    ipx, ipy = np.floor(spx), np.floor(spy)
+    fpx, fpy = fract(spx), fract(spy)
+    d = np.ones_like(px)
+    for y in (-1.0, 0.0, 1.0):
+        for x in (-1.0, 0.0, 1.0):
+            v = hash2(ipx + F(x), ipy + F(y))
+            ptx, pty = F(x) + v - fpx, F(y) + fract(v * F(17.0)) - fpy
+            d = np.minimum(d, ptx * ptx + pty * pty)
+    return np.sqrt(d)
+
+
+def simplex2d_wgsl(px, py):  # wgsl.rs:206-222
+    """The WebGPU emitter's simplex noise: gradients -1 + 2 fract(sin(dot(cell, k)) 43758.5453), fourth-power falloff, times 70."""
+    K1, K2 = F(0.366025404), F(0.211324865)
+
+    def grad(cx, cy):
+        qx = cx * F(127.1) + cy * F(311.7)
+        qy = cx * F(269.5) + cy * F(183.3)
+        return (F(-1.0) + F(2.0) * fract(sin32(qx) * F(43758.5453)), F(-1.0) + F(2.0) * fract(sin32(qy) * F(43758.5453)))
+    s = (px + py) * K1
+    ix, iy = np.floor(px + s), np.floor(py + s)
+    t = (ix + iy) * K2
+    ax, ay = px - ix + t, py - iy + t
+    ox = np.where(ax >= ay, F(1.0), F(0.0)).astype(np.float32)         # step(a.yx, a): 1 where the edge <= the value
+    oy = np.where(ay >= ax, F(1.0), F(0.0)).astype(np.float32)
+    bx, by = ax - ox + K2, ay - oy + K2
+    cx, cy = ax - F(1.0) + F(2.0) * K2, ay - F(1.0) + F(2.0) * K2
+    n = []
+    for (vx, vy), (gx, gy) in (((ax, ay), grad(ix, iy)), ((bx, by), grad(ix + ox, iy + oy)), ((cx, cy), grad(ix + F(1.0), iy + F(1.0)))):
+        hh = np.maximum(F(0.5) - (vx * vx + vy * vy), F(0.0))
+        n.append(hh * hh * hh * hh * (vx * gx + vy * gy))
+    return n[0] * F(70.0) + n[1] * F(70.0) + n[2] * F(70.0)
+
+
+def render_c2b_wgsl(w, h):
+    """render_c2b in the wording of the WebGPU emitter: same fbm and glow, the two noises above, same screen blend (wgsl.rs:259)."""
+    uvx, uvy = pixel_grid(w, h)
+    px, py = uvx * (F(w) / F(h)), uvy
+    glows = [apply_glow(fbm2(px * F(3.0), py * F(3.0), 4, 0.5, 2.0), 1.5),
+             apply_glow(simplex2d_wgsl(px * F(4.0), py * F(4.0)), 1.2),
+             apply_glow(voronoi2d_wgsl(px, py, 6.0), 1.0)]
+    fin = [np.zeros_like(px) for _ in range(3)]
+    for gl in glows:
+        lc = (gl * F(0.0), gl * F(1.0), gl * F(1.0))
+        fin = [fc + c - fc * c for fc, c in zip(fin, lc)]
+    return pack(fin[0], fin[1], fin[2], 1.0)
+
+
 def memory_mix(cur_rgba_float, prev_rgba8, decay):
     """memory.rs:38-45 on float colours; prev is RGBA8."""
     prev = quotient(prev_rgba8.astype(np.float32), F(255.0))   # byte times RN(1 / 255)

@@ -144,6 +144,16 @@ def test_c2b_frame_matches_numpy(game, oracle, w, h):
     assert np.array_equal(got, NP.render_c2b(w, h))
 
 
+@pytest.mark.parametrize("w,h", [(96, 54), (31, 40)])
+def test_c2b_frame_in_the_webgpu_wording_matches_numpy(game, oracle, w, h):
+    """The same cinematic as the reference's WebGPU emitter words it: arithmetic-hash voronoi (wgsl.rs:187-201) and
+    sine-gradient simplex (wgsl.rs:206-222); the two wordings give different pictures."""
+    cin = game.compile(C2B_NOISE).cinematics[0]
+    got = oracle.render(cin.blob, w, h, cin.uniform_rows([0.0], w, h)[0], threads=4, semantics="wgsl")
+    assert np.array_equal(got, NP.render_c2b_wgsl(w, h))
+    assert not np.array_equal(got, NP.render_c2b(w, h))
+
+
 def test_sine_of_the_render_path_matches_numpy(oracle):
     rng = np.random.default_rng(7)
     x = np.concatenate([rng.uniform(-32768, 32768, 20000), rng.uniform(-8, 8, 20000), [0.0, -0.0, 32768.0, -32768.0]]).astype(np.float32)
