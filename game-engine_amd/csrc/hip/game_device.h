@@ -471,8 +471,9 @@ GD void gd_fbm_cells(float px, float py, int octaves, float lacunarity, int firs
 // samples at (rotation^i p) * frequency_i, whose Euclidean norm is |p| * frequency_i up to a few ulps, so
 // |p|^2 * max(frequency)^2 <= 509^2 keeps every lattice cell of every octave within [-510, 510] (two cells of margin
 // inside the table; NaN fails the test). Where the folded recurrence will be used both coordinates must also be at
-// least 2^-40 in size: then one of q's coordinates stays above 2^-41 through every rotation (they preserve the norm), a
-// product with 0.8 or 0.6 is never subnormal, and a difference that cancels is zero or at least 2^-88 - nothing is
+// least 2^-40 in size - tested as |px py| >= 2^-30, one multiplication and one compare, which implies it because the norm
+// test has already bounded both by 509 < 2^9: then one of q's coordinates stays above 2^-41 through every rotation (they
+// preserve the norm), a product with 0.8 or 0.6 is never subnormal, and a difference that cancels is zero or at least 2^-88 - nothing is
 // subnormal in either form, so the folded and the literal cells agree bit for bit. (A coordinate of exactly zero would
 // be fine too; it takes the other path with the tiny ones, which costs the centre row and column of an odd-sized frame
 // a few hash evaluations.)
@@ -489,7 +490,7 @@ GD bool gd_fbm_table_ok(float px, float py, int octaves, float persistence, floa
         frequency = frequency * lacunarity;
     }
     bool ok = __builtin_fmaf(px, px, py * py) * (fmax * fmax) <= 259081.0f;
-    if (gd_fbm_folds(lacunarity)) ok = ok && gd_min(gd_abs(px), gd_abs(py)) >= 0x1p-40f;
+    if (gd_fbm_folds(lacunarity)) ok = ok && gd_abs(px * py) >= 0x1p-30f;
     return ok;
 }
 
@@ -840,17 +841,18 @@ GD void gb_domain_warp_rows(GdPix& s, float amount, float freq, GdWarpRows& k, c
     ca.ix = gd_floor(ax); ca.ux = fa * fa * __builtin_fmaf(-2.0f, fa, 3.0f); ca.iy = y.iy0; ca.uy = y.uy0;
     cb.ix = gd_floor(bx); cb.ux = fb * fb * __builtin_fmaf(-2.0f, fb, 3.0f); cb.iy = y.iy1; cb.uy = y.uy1;
     float n0, n1;
-    if (s.lut != nullptr && gd_abs(ca.ix) <= 511.0f && gd_abs(cb.ix) <= 511.0f && y.ok != 0.0f) {
-        if (ca.iy != k.iy0) {
-            ca.off = gd_lut_offset16(ca.ix, ca.iy, 0.0f);
-            GdCorners c = gd_corners_load(ca, s.lut);
-            k.lo0 = gd_edge_lo(c, ca.ux); k.d0 = gd_edge_hi(c, ca.ux) - k.lo0; k.iy0 = ca.iy;
-        }
-        if (cb.iy != k.iy1) {
-            cb.off = gd_lut_offset16(cb.ix, cb.iy, 0.0f);
-            GdCorners c = gd_corners_load(cb, s.lut);
-            k.lo1 = gd_edge_lo(c, cb.ux); k.d1 = gd_edge_hi(c, cb.ux) - k.lo1; k.iy1 = cb.iy;
-        }
+    const bool table = s.lut != nullptr && gd_abs(ca.ix) <= 511.0f && gd_abs(cb.ix) <= 511.0f && y.ok != 0.0f;
+    if (table && ca.iy != k.iy0) {
+        ca.off = gd_lut_offset16(ca.ix, ca.iy, 0.0f);
+        GdCorners c = gd_corners_load(ca, s.lut);
+        k.lo0 = gd_edge_lo(c, ca.ux); k.d0 = gd_edge_hi(c, ca.ux) - k.lo0; k.iy0 = ca.iy;
+    }
+    if (table && cb.iy != k.iy1) {
+        cb.off = gd_lut_offset16(cb.ix, cb.iy, 0.0f);
+        GdCorners c = gd_corners_load(cb, s.lut);
+        k.lo1 = gd_edge_lo(c, cb.ux); k.d1 = gd_edge_hi(c, cb.ux) - k.lo1; k.iy1 = cb.iy;
+    }
+    if (table) {
         n0 = __builtin_fmaf(__builtin_fmaf(y.uy0, k.d0, k.lo0), 2.0f, -1.0f);   // mix(lo, hi, uy) * 2 - 1
         n1 = __builtin_fmaf(__builtin_fmaf(y.uy1, k.d1, k.lo1), 2.0f, -1.0f);
     } else {
@@ -879,8 +881,8 @@ GD void gb_voronoi_rows(GdPix& s, float scale, GdVoronoiRows& k, const float* y)
     const float psx = s.px * scale;
     const float ipx = gd_floor(psx), fpx = gd_fract(psx);
     const float ipy = y[0], fpy = y[1];
-    if (!(s.vlut != nullptr && gd_abs(ipx) <= 510.0f && y[2] != 0.0f)) { s.sdf = gd_voronoi2d(s.px, s.py, scale); return; }
-    if (ipy != k.iy) {
+    const bool table = s.vlut != nullptr && gd_abs(ipx) <= 510.0f && y[2] != 0.0f;
+    if (table && ipy != k.iy) {
         const char* base = (const char*)s.vlut + gd_lut_offset(ipx, ipy, -1.0f);   // entry (ipy - 1, ipx - 1)
 #pragma unroll
         for (int yy = -1; yy <= 1; yy++) {
@@ -898,6 +900,7 @@ GD void gb_voronoi_rows(GdPix& s, float scale, GdVoronoiRows& k, const float* y)
         }
         k.iy = ipy;
     }
+    if (!table) { s.sdf = gd_voronoi2d(s.px, s.py, scale); return; }
     float d = 1.0f;
 #pragma unroll
     for (int c = 0; c < 9; c++) {
@@ -910,20 +913,21 @@ GD void gb_voronoi_rows(GdPix& s, float scale, GdVoronoiRows& k, const float* y)
 // lattice column, its x weight and - from row to row - its x-interpolated edge values stay.
 struct GdFbmRows { float iy, lo, d; };   // lattice row, mix(a, b, ux), mix(c, d, ux) - mix(a, b, ux) of octave 0
 GD void gd_fbm_rows_reset(GdFbmRows& k) { k.iy = __builtin_nanf(""); k.lo = k.d = 0.0f; }
-GD void gd_fbm_rows_y(float py, float scale, float* o)   // {lattice row, uy, -, -} of octave 0
+GD void gd_fbm_rows_y(float py, float scale, float* o)   // {lattice row, uy, row inside the table, -} of octave 0
 {
     const float a = py * scale;
     const float f = gd_fract(a);
-    o[0] = gd_floor(a); o[1] = f * f * __builtin_fmaf(-2.0f, f, 3.0f); o[2] = 0.0f; o[3] = 0.0f;
+    o[0] = gd_floor(a); o[1] = f * f * __builtin_fmaf(-2.0f, f, 3.0f); o[2] = gd_abs(o[0]) <= 511.0f ? 1.0f : 0.0f; o[3] = 0.0f;
 }
 GD void gb_fbm_rows(GdPix& s, float scale, int octaves, float persistence, float lacunarity, GdFbmRows& k, const float* y)
 {
     const float px = s.px * scale, py = s.py * scale;
-    if (!(s.lut != nullptr && __builtin_constant_p(octaves) && octaves >= 1 && octaves <= 8)) {
+    if (!(__builtin_constant_p(octaves) && octaves >= 1 && octaves <= 8)) {
         s.sdf = gd_fbm2(px, py, octaves, persistence, lacunarity, s.lut);
         return;
     }
-    // as gd_fbm2's table path; cell 0 (which samples at p * scale itself) takes its y half from the workgroup's row values
+    // as gd_fbm2's table path (without a table every pixel takes the hash branch below: one loop body either way, so
+    // that k stays in one set of registers); cell 0 (which samples at p * scale itself) takes its y half from the workgroup's row values
     GdCell cell[8];
     float amp[8];
     float max_val = 0.0f;
@@ -933,17 +937,23 @@ GD void gb_fbm_rows(GdPix& s, float scale, int octaves, float persistence, float
         cell[0].ux = fx * fx * __builtin_fmaf(-2.0f, fx, 3.0f); cell[0].uy = y[1];
     }
     float value = 0.0f;
-    if (gd_fbm_table_ok(px, py, octaves, persistence, lacunarity, amp, max_val)) {
+    const bool in_range = gd_fbm_table_ok(px, py, octaves, persistence, lacunarity, amp, max_val);
+    const bool table = s.lut != nullptr && in_range;
+    // The kept edge values follow cell 0 wherever that cell is inside the table, whether or not this pixel's other octaves
+    // are (the norm test implies it): a condition of its own keeps the refresh a plain masked update of k's registers.
+    const bool refresh = (s.lut != nullptr) & (gd_abs(cell[0].ix) <= 511.0f) & (y[2] != 0.0f) & (cell[0].iy != k.iy);
+    if (refresh) {
+        cell[0].off = gd_lut_offset16(cell[0].ix, cell[0].iy, 0.0f);
+        GdCorners c0 = gd_corners_load(cell[0], s.lut);
+        k.lo = gd_edge_lo(c0, cell[0].ux); k.d = gd_edge_hi(c0, cell[0].ux) - k.lo; k.iy = cell[0].iy;
+    }
+    const float n0 = __builtin_fmaf(__builtin_fmaf(y[1], k.d, k.lo), 2.0f, -1.0f);   // octave 0, taken here so that k is not live across the branch
+    if (table) {
         gd_fbm_cells(px, py, octaves, lacunarity, 1, cell, gd_fbm_folds(lacunarity));
         GdCorners c[8];
 #pragma unroll
         for (int i = 1; i < octaves; i++) c[i] = gd_corners_load(cell[i], s.lut);
-        if (cell[0].iy != k.iy) {
-            cell[0].off = gd_lut_offset16(cell[0].ix, cell[0].iy, 0.0f);
-            GdCorners c0 = gd_corners_load(cell[0], s.lut);
-            k.lo = gd_edge_lo(c0, cell[0].ux); k.d = gd_edge_hi(c0, cell[0].ux) - k.lo; k.iy = cell[0].iy;
-        }
-        value = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(y[1], k.d, k.lo), 2.0f, -1.0f), amp[0], value);
+        value = __builtin_fmaf(n0, amp[0], value);
 #pragma unroll
         for (int i = 1; i < octaves; i++) value = __builtin_fmaf(gd_noise2_combine(cell[i], c[i]), amp[i], value);
     } else {
