@@ -1,5 +1,8 @@
 #!/bin/bash
-# usage: ab_lib.sh <rounds> <config>...   alternates the two library builds on one box
+# Alternating bench.py runs of two builds of the library on one box: what a change in game_device.h is worth.
+# Build the two, copy them to game-engine_amd/libgame_hip_old.so and game-engine_amd/libgame_hip_new.so (they travel with
+# the tree; delete them and rebuild afterwards), then on the GPU box:
+# usage: tools/ab_lib.sh <rounds> <config>...
 rounds=$1; shift
 for r in $(seq $rounds); do
   for v in old new; do
