@@ -522,7 +522,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c2b", "c3", "c4", "c5"])
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c2b", "c3", "c3b", "c4", "c5"])
     ap.add_argument("--frames", type=int, default=0, help="frames per step on each GPU; default = the whole job of the config (c2: 1000)")
     ap.add_argument("--batch", type=int, default=0, help="frames per launch; default 25 (200 for the 1024x1024 config)")
     ap.add_argument("--particles", type=int, default=1048576)
@@ -550,7 +550,7 @@ def main():
         out = time_frames(args, game, torch, rank, world, local, args.config, args.steps, args.warmup, True)
     if rank == 0 and world == 1 and args.config == "c2" and not args.no_others and not args.frames and not args.batch:
         others = {}
-        for key, steps in (("c1", 100), ("c2b", 10), ("c3", 50), ("c4", 5)):
+        for key, steps in (("c1", 100), ("c2b", 10), ("c3", 50), ("c3b", 50), ("c4", 5)):
             others[key] = brief(time_frames(args, game, torch, rank, world, local, key, steps, 1, False))
         others["c5"] = brief(time_particles(args, game, torch, rank, world, local, 1048576, 3, 1, False))
         others["c5_fast"] = brief(time_particles(args, game, torch, rank, world, local, 1048576, 3, 1, False, fast=True))

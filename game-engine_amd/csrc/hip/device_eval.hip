@@ -107,7 +107,8 @@ __device__ float rsqrt_arbitrated(float x)
 // which: 0 = fract(x) for every bit pattern x; 1 = max(x, c), 2 = min(x, c) for every x and the
 // probe constants below; 3 = gd_sqrt(x), 4 = gd_rcp(x) against the compiler's IEEE expansions; 5 = gd_sqrt_rsqrt_core
 // against sqrtf(x) and the exactly arbitrated 1 / sqrt(x) for 2^-100 <= x < inf; 6 = v_cvt_pk_u8_f32 against the frame
-// store's definition; 7 = gd_rsqrt_core alone against the same arbitrated value.
+// store's definition; 7 = gd_rsqrt_core alone against the same arbitrated value; 8 = gd_reinhard(x) against x / (x + 1);
+// 9 = gw_aces_ratio(x) against the same quotient divided by the compiler.
 __global__ void exhaustive_kernel(int which, unsigned long long* mismatches, uint32_t* first_bad)
 {
     const float probes[6] = {0.0f, -0.0f, 1.0f, -1.0f, __builtin_inff(), __builtin_nanf("")};
@@ -124,6 +125,11 @@ __global__ void exhaustive_kernel(int which, unsigned long long* mismatches, uin
         } else if (which == 3 || which == 4) {
             float hw = which == 3 ? gd_sqrt(x) : gd_rcp(x);
             float want = which == 3 ? __builtin_sqrtf(x) : 1.0f / x;
+            bool same = (hw != hw && want != want) || gd_bits(hw) == gd_bits(want);
+            if (!same) { ++bad; atomicMin(first_bad, (gd_u32)v); }
+        } else if (which == 8 || which == 9) {
+            float hw = which == 8 ? gd_reinhard(x) : gw_aces_ratio(x);
+            float want = which == 8 ? x / (x + 1.0f) : (x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f);
             bool same = (hw != hw && want != want) || gd_bits(hw) == gd_bits(want);
             if (!same) { ++bad; atomicMin(first_bad, (gd_u32)v); }
         } else if (which == 6) {
@@ -255,7 +261,7 @@ int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out
 
 int game_hip_check_exhaustive(int which, uint64_t* mismatches, uint32_t* first_bad)
 {
-    if (which < 0 || which > 7 || !mismatches || !first_bad) return set_error(GAME_E_ARGUMENT, "game_hip_check_exhaustive: bad argument");
+    if (which < 0 || which > 9 || !mismatches || !first_bad) return set_error(GAME_E_ARGUMENT, "game_hip_check_exhaustive: bad argument");
     DevBuf dm, df;
     HIP_TRY(dm.alloc(8));
     HIP_TRY(df.alloc(4));

@@ -3,7 +3,7 @@
 Sources are inline because the machine that renders has no copy of the reference tree: C1, C3, C4 and C5 are the
 reference's examples/001-hello.game, 007-showcase.game, 003-memory-trails.game and 010-gravity-particles.game
 verbatim; C2 is the fbm showcase the headline metric is quoted on; C2B is examples/tutorial-05-noise.game without
-its comments. Frame k of every workload has u_time = k / 60 s, mouse = 0 and resolution = (w, h)."""
+its comments; C3B is C3 with a tonemap stage appended (the file has none). Frame k of every workload has u_time = k / 60 s, mouse = 0 and resolution = (w, h)."""
 import numpy as np
 
 C1_HELLO = '''cinematic "hello-glow" {
@@ -33,6 +33,8 @@ C3_SHOWCASE = '''cinematic "Showcase" {
     treble: 0.0 ~ audio.treble * 1.5
   }
 }'''
+# 007-showcase.game ends at grain; the same chain with the Reinhard tonemap (glsl.rs:473-478) appended
+C3B_SHOWCASE_TONEMAP = C3_SHOWCASE.replace("| grain(0.025)", "| grain(0.025)\n      | tonemap(1.0)")
 C4_TRAILS = '''cinematic "trails" {
   layer glow_core memory: 0.97 {
     translate(audio.bass, 0.0) | circle(0.1) | glow(2.5) | tint(1.0, 0.5, 0.2)
@@ -64,6 +66,8 @@ CONFIGS = {
                 workload="examples/tutorial-05-noise.game (fbm4 + simplex + voronoi, 3 layers), 3840x2160"),
     "c3": dict(src=C3_SHOWCASE, w=3840, h=2160, flops_px=95, bytes_px=4, bound="valu", frames=100, batch=25,
                workload="examples/007-showcase.game spectrum|bloom|chromatic|vignette|grain, 3840x2160 x 100 frames"),
+    "c3b": dict(src=C3B_SHOWCASE_TONEMAP, w=3840, h=2160, flops_px=102, bytes_px=4, bound="valu", frames=100, batch=25,
+                workload="examples/007-showcase.game with | tonemap(1.0) appended, 3840x2160 x 100 frames"),
     "c4": dict(src=C4_TRAILS, w=7680, h=4320, flops_px=59, bytes_px=8, bound="hbm", frames=300, batch=300,
                workload="examples/003-memory-trails.game feedback memory, 7680x4320 x 300 frames, frame-serial, band-sharded"),
 }
@@ -76,6 +80,6 @@ def frame_rows(cin, key, frame_indices, w, h):
     audio = None
     if key == "c4":
         audio = {"bass": 0.5 + 0.5 * np.sin(2 * np.pi * 0.5 * ks / 60.0)}
-    elif key == "c3":
+    elif key in ("c3", "c3b"):
         audio = {"bass": 0.8, "mid": 0.6, "treble": 0.4, "energy": 0.6}
     return cin.uniform_rows(ks / 60.0, w, h, audio=audio)

@@ -25,7 +25,9 @@ int game_hip_eval(int op, uint32_t n, const float* a, const float* b, float* out
  * v_min_f32 vs "NaN yields the other operand, -0 < +0" against probe constants; 3 / 4 = the short
  * v_rsq_f32 / v_rcp_f32 + fma sequences of the render path vs correctly rounded sqrt(x) and 1/x; 5 = the joint root / reciprocal-of-root
  * sequence of the gravity kernel vs sqrtf(x) and 1/sqrtf(x) for 2^-100 <= x < inf; 6 = v_cvt_pk_u8_f32 (the frame store) vs
- * "to the nearest integer, ties to even, saturated to [0, 255], NaN -> 0", in byte 0 of a zero word and byte 2 of an all-ones word. */
+ * "to the nearest integer, ties to even, saturated to [0, 255], NaN -> 0", in byte 0 of a zero word and byte 2 of an all-ones word;
+ * 7 = the reciprocal root alone against the exactly arbitrated 1/sqrt(x); 8 = the tonemap's short quotient x / (x + 1) vs the IEEE division;
+ * 9 = the same for the WebGPU wording's ACES quotient (x (2.51 x + 0.03)) / (x (2.43 x + 0.59) + 0.14). */
 int game_hip_check_exhaustive(int which, uint64_t* mismatches, uint32_t* first_bad);
 
 #ifdef __cplusplus

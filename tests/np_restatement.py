@@ -271,9 +271,10 @@ def render_c3_no_grain(w, h, bass, mid, treble):
     return pack(r * fac, g * fac, b * fac, 1.0)
 
 
-def render_c3(w, h, bass, mid, treble, time):
+def render_c3(w, h, bass, mid, treble, time, tonemap=None):
     """render_c3_no_grain followed by grain(0.025) (glsl.rs:453-457): every channel plus
-    (fract(sin(dot(p, (12.9898, 78.233)) + time) * 43758.5453) - 0.5) * amount; `time` is the wrapped shader time."""
+    (fract(sin(dot(p, (12.9898, 78.233)) + time) * 43758.5453) - 0.5) * amount; `time` is the wrapped shader time.
+    tonemap: exposure of a trailing Reinhard stage (glsl.rs:473-478), c * e / (c * e + 1) with a true division."""
     uvx, uvy = pixel_grid(w, h)
     sx = uvx * F(0.5) + F(0.5)
     r = smoothstep(0.0, 0.33, sx) * (F(bass) + F(0.0))
@@ -290,7 +291,11 @@ def render_c3(w, h, bass, mid, treble, time):
     r, g, b = r * fac, g * fac, b * fac
     px, py = uvx * (F(w) / F(h)), uvy
     n = (fract(sin32(px * F(12.9898) + py * F(78.233) + F(time)) * F(43758.5453)) - F(0.5)) * F(0.025)
-    return pack(r + n, g + n, b + n, 1.0)
+    r, g, b = r + n, g + n, b + n
+    if tonemap is not None:
+        with np.errstate(invalid="ignore", divide="ignore"):
+            r, g, b = ((c * F(tonemap)) / (c * F(tonemap) + F(1.0)) for c in (r, g, b))
+    return pack(r, g, b, 1.0)
 
 
 def render_c2b(w, h):

@@ -43,7 +43,7 @@ def test_device_present(game):
 
 
 # ── hardware instructions vs their defining formulas, all 2^32 inputs ───────────────────
-@pytest.mark.parametrize("which", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("which", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_exhaustive_instruction_semantics(game, which):
     mismatches, first = game.check_exhaustive(which)
     assert mismatches == 0, hex(first)
@@ -397,6 +397,27 @@ def test_c2_4k_bands_and_properties(game, oracle):
     band = r.render_band(rows[:1], 1000, 160)[0]
     assert np.array_equal(band, frames[0][1000:1160])
     r.close()
+
+
+def test_c3_and_c3b_4k_bands_and_properties(game, oracle):
+    """The showcase chain and the same chain with the tonemap stage appended (workloads c3, c3b) at 3840 x 2160: bands
+    against the oracle; the tonemap maps every channel c to c / (c + 1) rounded, so c3b is never brighter than c3."""
+    W = game.workloads
+    w, h = 3840, 2160
+    frames = {}
+    for key in ("c3", "c3b"):
+        cin = game.compile(W.CONFIGS[key]["src"]).cinematics[0]
+        rows = W.frame_rows(cin, key, [0, 37], w, h)
+        r = cin.renderer(w, h)
+        got = r.render(rows)
+        assert not np.array_equal(got[0], got[1])                                           # grain reads the time
+        for r0, n in ((0, 2), (1079, 2), (2158, 2)):
+            assert np.array_equal(got[1][r0:r0 + n], oracle.render(cin.blob, w, h, rows[1], row0=r0, rows=n))
+        assert np.array_equal(r.render_band(rows[1:], 1000, 96)[0], got[1][1000:1096])
+        r.close()
+        frames[key] = got[1]
+    assert (frames["c3b"][..., :3] <= frames["c3"][..., :3]).all() and (frames["c3b"][..., :3] < frames["c3"][..., :3]).any()
+    assert (frames["c3b"][..., 3] == 255).all()
 
 
 def test_c4_8k_feedback_recurrence(game, oracle):

@@ -135,6 +135,16 @@ def test_c3_frame_matches_numpy_with_grain(game, oracle):
     assert not np.array_equal(NP.render_c3(96, 54, 0.8, 0.6, 0.4, 0.0), NP.render_c3_no_grain(96, 54, 0.8, 0.6, 0.4))
 
 
+def test_c3b_frame_matches_numpy(game, oracle):
+    """The showcase chain with the tonemap stage the file lacks appended (workload c3b)."""
+    from conftest import _W
+    audio = {"bass": 0.8, "mid": 0.6, "treble": 0.4, "energy": 0.6}
+    got, cin = frame(game, oracle, _W.C3B_SHOWCASE_TONEMAP, 96, 54, t=1.5, audio=audio)
+    assert [st["name"] for st in cin.ir["layers"][0]["stages"]][-2:] == ["grain", "tonemap"]
+    assert np.array_equal(got, NP.render_c3(96, 54, 0.8, 0.6, 0.4, 1.5, tonemap=1.0))
+    assert not np.array_equal(got, NP.render_c3(96, 54, 0.8, 0.6, 0.4, 1.5))
+
+
 @pytest.mark.parametrize("w,h", [(96, 54), (31, 40)])
 def test_c2b_frame_matches_numpy(game, oracle, w, h):
     """examples/tutorial-05-noise.game: fbm, the permute-289 simplex, the sine-hash voronoi and the screen blend of
